@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the GGUF dequantize hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--out f32|f16|bf16]
+
+One "step" decodes one whole synthetic tensor set that is already resident in HBM
+(packed blocks in, f32 out), through the C ABI (ggq_batch_run: one kernel launch
+per block type present).  Default workload: the Llama-7B-shaped tensor set under
+the Q4_K_M type mixture (6.74 G elements, 226 tensors, Q4_K + Q6_K).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the job is N such sets
+(weak scaling), dealt to the ranks by the index partition of gguf_amd.shard; no
+collective takes part in the data path, the process group is used for the barriers
+around the timed region and for the max-over-ranks of the time.
+
+Prints ONE JSON line on rank 0.  `value` = decoded (output) bytes of the whole job
+per second.  `roofline` prices the dominant kernel (the Q4_K launch) in algorithmic
+bytes = elements x (block_bytes/block_elems + sizeof(out)) against 8 TB/s, with the
+launch duration measured by HIP events on the launch stream inside the timed region.
+`cpu_baseline` times the CPU oracle (a port of the reference's per-block decode) on
+this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="llama7b_q4_k_m")
+    ap.add_argument("--out", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(items, out_ty_name, budget_s):
+    """Oracle (C port of the reference decode, blocks split over a thread pool like the
+    reference's rayon loop) on a bounded sample: the leading tensors of the workload up
+    to ~0.4 G elements, decoded repeatedly for about `budget_s` seconds; best pass."""
+    import numpy as np
+    import oracle as o
+    from gguf_amd import synth
+    from gguf_amd.quants import block_bytes, block_elems
+    o.build()
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    out_ty = {"f32": o.F32, "f16": o.F16, "bf16": o.BF16}[out_ty_name]
+    ob = 4 if out_ty_name == "f32" else 2
+    sample, elems = [], 0
+    for name, ty, n in items:
+        sample.append((name, ty, n))
+        elems += n
+        if elems >= 400_000_000:
+            break
+    bufs = []
+    for i, (name, ty, n) in enumerate(sample):
+        blocks = n // block_elems(ty)
+        # payload content does not change the decode's cost; tile a 4 MiB random chunk
+        chunk = synth.random_blocks(ty, min(blocks, (4 << 20) // block_bytes(ty)), 0xC0FFEE04 + i)
+        reps = -(-blocks * block_bytes(ty) // chunk.size)
+        packed = np.tile(chunk, reps)[: blocks * block_bytes(ty)]
+        dst = np.zeros(n, dtype=np.float32 if ob == 4 else np.uint16)   # pre-faulted
+        bufs.append((int(ty), packed, dst, blocks))
+    best = float("inf")
+    passes = 0
+    t_end = time.perf_counter() + budget_s
+    while passes < 2 or (time.perf_counter() < t_end and passes < 20):
+        t0 = time.perf_counter()
+        for ty, packed, dst, blocks in bufs:
+            st = o.dequantize_status(ty, out_ty, dst, dst.size, packed, blocks, threads=cores)
+            assert st == 0
+        best = min(best, time.perf_counter() - t0)
+        passes += 1
+    types = sorted({o_ty for o_ty, _, _, _ in bufs})
+    return {
+        "value": round(elems * ob / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "melem_per_s": round(elems / best / 1e6, 1),
+        "sample": f"first {len(sample)} tensors of the workload ({elems} elements, ggml types {types}), "
+                  f"pre-faulted output, best of {passes} passes",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import gguf_amd as g
+    from gguf_amd import shard, synth
+    from gguf_amd.quants import GGmlType, block_bytes, block_elems
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- the job: `world` tensor sets, dealt to ranks by the index partition -------
+    base = synth.workload(args.workload)
+    items = [(f"set{r}.{n}", ty, ne) for r in range(world) for (n, ty, ne) in base]
+    mine = shard.partition(items, world)[rank]
+    out_dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.out]
+    ob = 4 if args.out == "f32" else 2
+    out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[args.out]
+
+    my_elems = sum(p.elems for p in mine)
+    dst_all = torch.empty(my_elems, dtype=out_dt, device=dev)
+    by_type = {}
+    at = 0
+    for i, p in enumerate(mine):
+        src = synth.random_blocks_device(p.ggml_type, p.blocks, 0xC0FFEE04 + 1000 * rank + i, dev)
+        dst = dst_all[at:at + p.elems]
+        at += p.elems
+        by_type.setdefault(p.ggml_type, []).append((p.ggml_type, src, dst))
+    # one launch plan per block type, so each kernel can be timed on its own
+    order = sorted(by_type, key=lambda t: -sum(x[2].numel() for x in by_type[t]))
+    plans = [(ty, g.Batch(by_type[ty], out_ty)) for ty in order]
+    launches = sum(b.launches for _, b in plans)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        for _, b in plans:
+            b.run(stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # HIP events on the launch stream, around every kernel of every timed step
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(plans) + 1)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        for k, (_, b) in enumerate(plans):
+            b.run(stream)
+            ev[s][k + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel launch durations (ms), averaged over the timed steps
+    kern_ms = []
+    for k in range(len(plans)):
+        kern_ms.append(sum(ev[s][k].elapsed_time(ev[s][k + 1]) for s in range(args.steps)) / args.steps)
+
+    if rank == 0:
+        total_elems = sum(ne for _, _, ne in items)
+        pin, pout, _ = synth.workload_bytes(items, ob)
+        ms = elapsed / args.steps * 1e3
+        dom_ty = order[0]
+        dom_elems = sum(x[2].numel() for x in by_type[dom_ty])
+        per_elem = block_bytes(dom_ty) / block_elems(dom_ty) + ob
+        dom_bytes = dom_elems * per_elem
+        achieved = dom_bytes / (kern_ms[0] * 1e-3) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                key = f"{args.workload}:{args.out}:{GGmlType(dom_ty).name}"
+                traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        rec = {
+            "metric": "dequantized_GBps", "value": round(pout / (elapsed / args.steps) / 1e9, 2), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8->" + args.out, "data": "synthetic",
+            "config": {"workload": args.workload if world == 1 else f"{world} x {args.workload}",
+                       "tensors": len(items), "elements": total_elems, "packed_bytes": pin,
+                       "decoded_bytes": pout, "partition": "index (LPT), no collective",
+                       "kernel_launches_per_step": launches},
+            "melem_per_s": round(total_elems / (elapsed / args.steps) / 1e6, 1),
+            "packed_GBps": round(pin / (elapsed / args.steps) / 1e9, 2),
+            "algorithmic_GBps": round((pin + pout) / (elapsed / args.steps) / 1e9, 2),
+            "kernels": [{"type": GGmlType(ty).name, "elements": sum(x[2].numel() for x in by_type[ty]),
+                         "avg_ms": round(kern_ms[k], 4)} for k, ty in enumerate(order)],
+            "roofline": {"bound": "hbm", "kernel": f"deq_tiles_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(kern_ms[0], 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            for _, b in plans:
+                b.close()
+            del dst_all, by_type, plans
+            torch.cuda.empty_cache()
+            rec["cpu_baseline"] = cpu_baseline(base, args.out, args.cpu_seconds)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""ctypes binding of libggq.so, the C-ABI product library (include/ggq.h).
+
+There is no fallback: if the library has not been built, importing this module
+raises; if no HIP device is usable, compute calls return GGQ_DEVICE, which the
+wrappers in gguf_amd.quants turn into DeviceError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libggq.so")
+
+OK, INDIVISIBLE, LENGTH_MISMATCH, UNSUPPORTED, DEVICE, MISALIGNED, INVALID = range(7)
+
+
+class ggq_tensor(ctypes.Structure):
+    _fields_ = [("ggml_type", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("d_src", ctypes.c_void_p), ("d_dst", ctypes.c_void_p),
+                ("blocks", ctypes.c_uint64)]
+
+
+# every symbol include/ggq.h declares: name -> (restype, argtypes)
+_vp, _sz, _u32, _int = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+SYMBOLS = {
+    "ggq_block_elems": (_sz, [_u32]),
+    "ggq_block_bytes": (_sz, [_u32]),
+    "ggq_type_name": (ctypes.c_char_p, [_u32]),
+    "ggq_elements_to_bytes": (_int, [_u32, ctypes.POINTER(ctypes.c_uint64), _sz,
+                                     ctypes.POINTER(ctypes.c_uint64)]),
+    "ggq_status_str": (ctypes.c_char_p, [_int]),
+    "ggq_last_error": (ctypes.c_char_p, []),
+    "ggq_device_count": (_int, []),
+    "ggq_dequantize_slice": (_int, [_u32, _u32, _vp, _sz, _vp, _sz]),
+    "ggq_dequantize_device": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
+    "ggq_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
+    "ggq_batch_run": (_int, [_vp, _vp]),
+    "ggq_batch_launches": (_sz, [_vp]),
+    "ggq_batch_destroy": (None, [_vp]),
+    "ggq_ctx_create": (_int, [_int, _sz, ctypes.POINTER(_vp)]),
+    "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),
+    "ggq_sync": (_int, [_vp]),
+    "ggq_ctx_destroy": (None, [_vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C gguf_amd/csrc` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "gguf_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args

@@ -1,0 +1,618 @@
+// ggq_api.hip -- host side of libggq: argument checks in the reference's order,
+// kernel dispatch, the pinned-staging pipelines and the batch planner.
+// The C ABI is declared in include/ggq.h, which cites the reference interface
+// each entry point replaces.
+#include "../../include/ggq.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace ggq;
+
+namespace {
+
+// Non-temporal stores for the decoded output: it is written once and never
+// re-read by this library, so it should not displace anything in L2 / MALL.
+#ifndef GGQ_NT_STORES
+#define GGQ_NT_STORES 1
+#endif
+constexpr bool kNT = GGQ_NT_STORES != 0;
+
+thread_local std::string g_err;
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return false;
+}
+#define HIP_TRY(call)                                  \
+    do {                                               \
+        if (!hip_ok((call), #call)) return GGQ_DEVICE; \
+    } while (0)
+
+struct TypeInfo {
+    uint32_t id, elems, bytes;
+    const char *name;
+};
+// (id, elements per block, bytes per block, layout name).  Bytes are size_of
+// the reference's #[repr(C)] structs, except IQ4NL / IQ4XS: the reference
+// structs declare u16 quants (34 / 264 bytes) where GGUF files hold the ggml
+// blocks of 18 / 136 bytes; the file format wins.
+const TypeInfo kTypes[] = {
+    {GGQ_TYPE_F16, 1, 2, "f16"},      {GGQ_TYPE_BF16, 1, 2, "bf16"},
+    {GGQ_TYPE_Q4_0, 32, 18, "q40"},   {GGQ_TYPE_Q4_1, 32, 20, "q41"},
+    {GGQ_TYPE_Q5_0, 32, 22, "q50"},   {GGQ_TYPE_Q5_1, 32, 24, "q51"},
+    {GGQ_TYPE_Q8_0, 32, 34, "q80"},   {GGQ_TYPE_Q8_1, 32, 36, "q81"},
+    {GGQ_TYPE_Q2K, 256, 84, "q2k"},   {GGQ_TYPE_Q3K, 256, 110, "q3k"},
+    {GGQ_TYPE_Q4K, 256, 144, "q4k"},  {GGQ_TYPE_Q5K, 256, 176, "q5k"},
+    {GGQ_TYPE_Q6K, 256, 210, "q6k"},  {GGQ_TYPE_Q8K, 256, 290, "q8k"},
+    {GGQ_TYPE_IQ4NL, 32, 18, "iq4nl"}, {GGQ_TYPE_IQ4XS, 256, 136, "iq4xs"},
+};
+
+const TypeInfo *type_info(uint32_t ty) {
+    for (const TypeInfo &t : kTypes)
+        if (t.id == ty) return &t;
+    return nullptr;
+}
+
+size_t out_bytes(uint32_t out_ty) {
+    return out_ty == GGQ_TYPE_F32 ? 4 : (out_ty == GGQ_TYPE_F16 || out_ty == GGQ_TYPE_BF16) ? 2 : 0;
+}
+
+// Checks shared by every dequantize entry point, in the order of
+// ggml-quants/src/lib.rs:136-141.
+ggq_status check_slice(uint32_t ty, uint32_t out_ty, size_t dst_elems, size_t src_blocks) {
+    const TypeInfo *ti = type_info(ty);
+    if (!ti || out_bytes(out_ty) == 0) return GGQ_UNSUPPORTED;
+    if (dst_elems % ti->elems != 0) return GGQ_INDIVISIBLE;
+    if (src_blocks != dst_elems / ti->elems) return GGQ_LENGTH_MISMATCH;
+    return GGQ_OK;
+}
+
+// ---- device properties (per device, cached) -----------------------------------
+struct DevInfo {
+    int cus = 0;
+};
+std::mutex g_dev_mu;
+std::vector<DevInfo> g_dev;
+
+ggq_status dev_info(int dev, DevInfo &out) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if ((size_t)dev >= g_dev.size()) g_dev.resize(dev + 1);
+    if (g_dev[dev].cus == 0) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        g_dev[dev].cus = cus > 0 ? cus : 256;
+    }
+    out = g_dev[dev];
+    return GGQ_OK;
+}
+
+// Workgroups for `ntiles` wave tiles: one wave per tile until the chip is full
+// (8 workgroups of 4 waves per CU), then waves walk several tiles each.
+uint32_t grid_for(uint64_t ntiles, int cus) {
+    uint64_t wgs = (ntiles + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    uint64_t cap = (uint64_t)cus * 8;
+    return (uint32_t)std::max<uint64_t>(1, std::min(wgs, cap));
+}
+
+#define GGQ_FORMATS(X)                                                                      \
+    X(GGQ_TYPE_Q4_0, Q4_0) X(GGQ_TYPE_Q4_1, Q4_1) X(GGQ_TYPE_Q5_0, Q5_0) X(GGQ_TYPE_Q5_1, Q5_1) \
+    X(GGQ_TYPE_Q8_0, Q8_0) X(GGQ_TYPE_Q8_1, Q8_1) X(GGQ_TYPE_Q2K, Q2K) X(GGQ_TYPE_Q3K, Q3K)     \
+    X(GGQ_TYPE_Q4K, Q4K) X(GGQ_TYPE_Q5K, Q5K) X(GGQ_TYPE_Q6K, Q6K) X(GGQ_TYPE_Q8K, Q8K)         \
+    X(GGQ_TYPE_IQ4NL, IQ4NL) X(GGQ_TYPE_IQ4XS, IQ4XS)
+
+// ---- single tensor --------------------------------------------------------------
+template <class O>
+ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t blocks, int cus,
+                         hipStream_t st) {
+    switch (ty) {
+#define X(ID, F)                                                                              \
+    case ID: {                                                                                \
+        uint64_t ntiles = (blocks + TileGeom<F>::TB - 1) / TileGeom<F>::TB;                   \
+        hipLaunchKernelGGL((deq_tiles<F, O, kNT>), dim3(grid_for(ntiles, cus)), dim3(WG_THREADS), \
+                           0, st, (const uint8_t *)d_src, (typename O::T *)d_dst, blocks);    \
+        break;                                                                                \
+    }
+        GGQ_FORMATS(X)
+#undef X
+    default:
+        return GGQ_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
+template <bool BF16SRC, class O>
+ggq_status launch_widen(void *d_dst, const void *d_src, uint64_t n, int cus, hipStream_t st) {
+    typedef typename O::T T;
+    const bool fast = ((uintptr_t)d_src % 8 == 0);
+    uint64_t n4 = fast ? n / 4 : 0;
+    if (n4) {
+        uint64_t wgs = (n4 + WG_THREADS - 1) / WG_THREADS;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)cus * 8);
+        hipLaunchKernelGGL((widen_vec<BF16SRC, O, kNT>), dim3(grid), dim3(WG_THREADS), 0, st,
+                           (const uint2 *)d_src, (T *)d_dst, n4);
+    }
+    if (n4 * 4 < n) {
+        uint64_t restn = n - n4 * 4;
+        uint64_t wgs = (restn + WG_THREADS - 1) / WG_THREADS;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)cus * 8);
+        hipLaunchKernelGGL((widen_scalar<BF16SRC, O>), dim3(grid), dim3(WG_THREADS), 0, st,
+                           (const uint16_t *)d_src, (T *)d_dst, n4 * 4, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
+template <class O>
+ggq_status launch_any(uint32_t ty, void *d_dst, const void *d_src, uint64_t blocks, int cus,
+                      hipStream_t st) {
+    if (blocks == 0) return GGQ_OK;
+    if (ty == GGQ_TYPE_F16) return launch_widen<false, O>(d_dst, d_src, blocks, cus, st);
+    if (ty == GGQ_TYPE_BF16) return launch_widen<true, O>(d_dst, d_src, blocks, cus, st);
+    return launch_blocks<O>(ty, d_dst, d_src, blocks, cus, st);
+}
+
+ggq_status launch_out(uint32_t ty, uint32_t out_ty, void *d_dst, const void *d_src, uint64_t blocks,
+                      int cus, hipStream_t st) {
+    switch (out_ty) {
+    case GGQ_TYPE_F32: return launch_any<OutF32>(ty, d_dst, d_src, blocks, cus, st);
+    case GGQ_TYPE_F16: return launch_any<OutF16>(ty, d_dst, d_src, blocks, cus, st);
+    case GGQ_TYPE_BF16: return launch_any<OutBF16>(ty, d_dst, d_src, blocks, cus, st);
+    default: return GGQ_UNSUPPORTED;
+    }
+}
+
+// ---- batch ------------------------------------------------------------------------
+template <class O>
+ggq_status launch_batch(uint32_t ty, const Segment *d_seg, uint32_t nseg, uint64_t ntiles, int cus,
+                        hipStream_t st) {
+    switch (ty) {
+#define X(ID, F)                                                                                 \
+    case ID:                                                                                     \
+        hipLaunchKernelGGL((deq_tiles_batch<F, O, kNT>), dim3(grid_for(ntiles, cus)),            \
+                           dim3(WG_THREADS), 0, st, d_seg, nseg, ntiles);                        \
+        break;
+        GGQ_FORMATS(X)
+#undef X
+    default:
+        return GGQ_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
+uint32_t tile_blocks(uint32_t ty) {
+    switch (ty) {
+#define X(ID, F) \
+    case ID: return TileGeom<F>::TB;
+        GGQ_FORMATS(X)
+#undef X
+    default: return 0;
+    }
+}
+
+}  // namespace
+
+struct ggq_batch {
+    int device = 0;
+    int cus = 0;
+    uint32_t out_ty = 0;
+    struct Group {
+        uint32_t ty;
+        uint32_t first, count;   // range in the device segment table
+        uint64_t ntiles;
+    };
+    std::vector<Group> groups;
+    // F16 / BF16 tensors are widened one launch each
+    struct Plain {
+        uint32_t ty;
+        const void *src;
+        void *dst;
+        uint64_t n;
+    };
+    std::vector<Plain> plain;
+    Segment *d_seg = nullptr;
+};
+
+// ---- pinned staging pipeline (host-buffer entry point and ggq_ctx) ----------------
+struct ggq_ctx {
+    int device = 0;
+    int cus = 0;
+    static constexpr int SLOTS = 2;
+    size_t in_cap = 0;      // bytes per slot, packed input
+    size_t out_cap = 0;     // bytes per slot, decoded output (0 for a decode-only context)
+    hipStream_t stream[SLOTS] = {};
+    hipEvent_t done[SLOTS] = {};
+    uint8_t *h_in[SLOTS] = {};
+    uint8_t *d_in[SLOTS] = {};
+    uint8_t *h_out[SLOTS] = {};
+    uint8_t *d_out[SLOTS] = {};
+    bool busy[SLOTS] = {};
+};
+
+namespace {
+
+void ctx_free(ggq_ctx *c) {
+    if (!c) return;
+    for (int s = 0; s < ggq_ctx::SLOTS; ++s) {
+        if (c->stream[s]) (void)hipStreamSynchronize(c->stream[s]);
+        if (c->h_in[s]) (void)hipHostFree(c->h_in[s]);
+        if (c->h_out[s]) (void)hipHostFree(c->h_out[s]);
+        if (c->d_in[s]) (void)hipFree(c->d_in[s]);
+        if (c->d_out[s]) (void)hipFree(c->d_out[s]);
+        if (c->done[s]) (void)hipEventDestroy(c->done[s]);
+        if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
+    }
+    delete c;
+}
+
+// in_cap: packed bytes per slot; out_cap: decoded bytes per slot staged back to
+// the host (0 = the decoded tensor stays on the device).
+ggq_status ctx_make(int device, size_t in_cap, size_t out_cap, ggq_ctx **out) {
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    ggq_ctx *c = new (std::nothrow) ggq_ctx();
+    if (!c) return GGQ_INVALID;
+    c->device = device;
+    DevInfo di;
+    ggq_status st = dev_info(device, di);
+    if (st != GGQ_OK) { delete c; return st; }
+    c->cus = di.cus;
+    c->in_cap = in_cap;
+    c->out_cap = out_cap;
+    bool ok = true;
+    for (int s = 0; s < ggq_ctx::SLOTS && ok; ++s) {
+        ok = ok && hip_ok(hipStreamCreateWithFlags(&c->stream[s], hipStreamNonBlocking), "hipStreamCreate");
+        ok = ok && hip_ok(hipEventCreateWithFlags(&c->done[s], hipEventDisableTiming), "hipEventCreate");
+        ok = ok && hip_ok(hipHostMalloc((void **)&c->h_in[s], in_cap + 32, hipHostMallocDefault), "hipHostMalloc");
+        ok = ok && hip_ok(hipMalloc((void **)&c->d_in[s], in_cap + 32), "hipMalloc");
+        if (out_cap) {
+            ok = ok && hip_ok(hipHostMalloc((void **)&c->h_out[s], out_cap, hipHostMallocDefault), "hipHostMalloc");
+            ok = ok && hip_ok(hipMalloc((void **)&c->d_out[s], out_cap), "hipMalloc");
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (!ok) { ctx_free(c); return GGQ_DEVICE; }
+    *out = c;
+    return GGQ_OK;
+}
+
+// Pool of host-buffer pipelines, one list per device; a call borrows one and
+// returns it.  Never torn down: freeing HIP objects from static destructors
+// races the runtime's own shutdown.
+std::mutex g_pool_mu;
+std::vector<std::vector<ggq_ctx *>> *g_pool = nullptr;
+
+constexpr size_t kHostChunkElems = 4u << 20;   // decoded elements per staged chunk
+
+ggq_status pool_get(int device, ggq_ctx **out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool) g_pool = new std::vector<std::vector<ggq_ctx *>>();
+        if ((size_t)device >= g_pool->size()) g_pool->resize(device + 1);
+        auto &v = (*g_pool)[device];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            return GGQ_OK;
+        }
+    }
+    // worst case bytes per element of packed input is Q8K's 290/256 (< 2)
+    return ctx_make(device, kHostChunkElems * 2, kHostChunkElems * 4, out);
+}
+
+void pool_put(ggq_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    (*g_pool)[c->device].push_back(c);
+}
+
+}  // namespace
+
+// =================================== C ABI =======================================
+extern "C" {
+
+size_t ggq_block_elems(uint32_t ty) {
+    const TypeInfo *t = type_info(ty);
+    return t ? t->elems : 0;
+}
+
+size_t ggq_block_bytes(uint32_t ty) {
+    const TypeInfo *t = type_info(ty);
+    return t ? t->bytes : 0;
+}
+
+const char *ggq_type_name(uint32_t ty) {
+    const TypeInfo *t = type_info(ty);
+    return t ? t->name : nullptr;
+}
+
+ggq_status ggq_elements_to_bytes(uint32_t ty, const uint64_t *shape, size_t ndim, uint64_t *bytes_out) {
+    if (!bytes_out || (ndim && !shape)) return GGQ_INVALID;
+    uint64_t blk, ele;
+    if (ty == GGQ_TYPE_F32) { blk = 1; ele = 4; }
+    else {
+        const TypeInfo *t = type_info(ty);
+        if (!t) return GGQ_UNSUPPORTED;
+        blk = t->elems; ele = t->bytes;
+    }
+    if (ndim == 0) {
+        if (blk != 1) return GGQ_INDIVISIBLE;
+        *bytes_out = ele;
+        return GGQ_OK;
+    }
+    if (shape[0] % blk != 0) return GGQ_INDIVISIBLE;
+    uint64_t others = 1;
+    for (size_t i = 1; i < ndim; ++i) others *= shape[i];
+    *bytes_out = others * shape[0] / blk * ele;
+    return GGQ_OK;
+}
+
+const char *ggq_status_str(ggq_status st) {
+    switch (st) {
+    case GGQ_OK: return "ok";
+    case GGQ_INDIVISIBLE: return "indivisible: element count is not a multiple of the block size";
+    case GGQ_LENGTH_MISMATCH: return "length mismatch: block count does not match element count";
+    case GGQ_UNSUPPORTED: return "unsupported type";
+    case GGQ_DEVICE: return "HIP device error";
+    case GGQ_MISALIGNED: return "device pointer is not aligned as required";
+    case GGQ_INVALID: return "invalid argument";
+    }
+    return "unknown status";
+}
+
+const char *ggq_last_error(void) { return g_err.c_str(); }
+
+int ggq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+ggq_status ggq_dequantize_device(uint32_t ty, uint32_t out_ty, void *d_dst, size_t dst_elems,
+                                 const void *d_src, size_t src_blocks, void *hip_stream) {
+    ggq_status st = check_slice(ty, out_ty, dst_elems, src_blocks);
+    if (st != GGQ_OK) return st;
+    if (src_blocks == 0) return GGQ_OK;
+    if (!d_dst || !d_src) return GGQ_INVALID;
+    if ((uintptr_t)d_dst % 16 != 0) return GGQ_MISALIGNED;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DevInfo di;
+    st = dev_info(dev, di);
+    if (st != GGQ_OK) return st;
+    return launch_out(ty, out_ty, d_dst, d_src, src_blocks, di.cus, (hipStream_t)hip_stream);
+}
+
+ggq_status ggq_dequantize_slice(uint32_t ty, uint32_t out_ty, void *dst, size_t dst_elems,
+                                const void *src, size_t src_blocks) {
+    ggq_status st = check_slice(ty, out_ty, dst_elems, src_blocks);
+    if (st != GGQ_OK) return st;
+    if (src_blocks == 0) return GGQ_OK;
+    if (!dst || !src) return GGQ_INVALID;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ggq_ctx *c = nullptr;
+    st = pool_get(dev, &c);
+    if (st != GGQ_OK) return st;
+
+    const TypeInfo *ti = type_info(ty);
+    const size_t ob = out_bytes(out_ty);
+    // blocks per chunk: whole tiles, so every chunk's output offset stays 16-byte aligned
+    size_t chunk_blocks = kHostChunkElems / ti->elems;
+    const uint8_t *s = (const uint8_t *)src;
+    uint8_t *d = (uint8_t *)dst;
+
+    struct Pending { size_t out_off, out_len; } pend[ggq_ctx::SLOTS] = {};
+    ggq_status rc = GGQ_OK;
+    size_t done_blocks = 0;
+    int slot = 0;
+    auto drain = [&](int k) -> bool {
+        if (!c->busy[k]) return true;
+        c->busy[k] = false;
+        if (!hip_ok(hipEventSynchronize(c->done[k]), "hipEventSynchronize")) return false;
+        memcpy(d + pend[k].out_off, c->h_out[k], pend[k].out_len);
+        return true;
+    };
+    while (done_blocks < src_blocks && rc == GGQ_OK) {
+        size_t nb = std::min(chunk_blocks, src_blocks - done_blocks);
+        size_t in_len = nb * ti->bytes, out_len = nb * ti->elems * ob;
+        if (!drain(slot)) { rc = GGQ_DEVICE; break; }
+        memcpy(c->h_in[slot], s + done_blocks * ti->bytes, in_len);
+        hipStream_t q = c->stream[slot];
+        bool ok = hip_ok(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], in_len, hipMemcpyHostToDevice, q), "H2D");
+        if (ok) {
+            rc = launch_out(ty, out_ty, c->d_out[slot], c->d_in[slot], nb, c->cus, q);
+            ok = rc == GGQ_OK;
+        }
+        ok = ok && hip_ok(hipMemcpyAsync(c->h_out[slot], c->d_out[slot], out_len, hipMemcpyDeviceToHost, q), "D2H");
+        ok = ok && hip_ok(hipEventRecord(c->done[slot], q), "hipEventRecord");
+        if (!ok) { if (rc == GGQ_OK) rc = GGQ_DEVICE; break; }
+        c->busy[slot] = true;
+        pend[slot] = {done_blocks * ti->elems * ob, out_len};
+        done_blocks += nb;
+        slot ^= 1;
+    }
+    for (int k = 0; k < ggq_ctx::SLOTS; ++k) {
+        int kk = (slot + k) % ggq_ctx::SLOTS;   // oldest first
+        if (rc == GGQ_OK) { if (!drain(kk)) rc = GGQ_DEVICE; }
+        else { (void)hipStreamSynchronize(c->stream[kk]); c->busy[kk] = false; }
+    }
+    pool_put(c);
+    return rc;
+}
+
+// ---- batch ------------------------------------------------------------------------
+ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t out_ty, ggq_batch **out) {
+    if (!out || (count && !tensors)) return GGQ_INVALID;
+    if (out_bytes(out_ty) == 0) return GGQ_UNSUPPORTED;
+    for (size_t i = 0; i < count; ++i) {
+        if (!type_info(tensors[i].ggml_type)) return GGQ_UNSUPPORTED;
+        if (tensors[i].blocks && (!tensors[i].d_src || !tensors[i].d_dst)) return GGQ_INVALID;
+        if ((uintptr_t)tensors[i].d_dst % 16 != 0) return GGQ_MISALIGNED;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DevInfo di;
+    ggq_status st = dev_info(dev, di);
+    if (st != GGQ_OK) return st;
+
+    ggq_batch *b = new (std::nothrow) ggq_batch();
+    if (!b) return GGQ_INVALID;
+    b->device = dev;
+    b->cus = di.cus;
+    b->out_ty = out_ty;
+
+    // group by type, keeping the caller's order inside a group
+    std::vector<uint32_t> types;
+    for (size_t i = 0; i < count; ++i) {
+        uint32_t ty = tensors[i].ggml_type;
+        if (tensors[i].blocks == 0) continue;
+        if (ty == GGQ_TYPE_F16 || ty == GGQ_TYPE_BF16) {
+            b->plain.push_back({ty, tensors[i].d_src, tensors[i].d_dst, tensors[i].blocks});
+            continue;
+        }
+        if (std::find(types.begin(), types.end(), ty) == types.end()) types.push_back(ty);
+    }
+    std::vector<Segment> segs;
+    for (uint32_t ty : types) {
+        ggq_batch::Group g{ty, (uint32_t)segs.size(), 0, 0};
+        uint32_t tb = tile_blocks(ty);
+        uint64_t tile = 0;
+        for (size_t i = 0; i < count; ++i) {
+            if (tensors[i].ggml_type != ty || tensors[i].blocks == 0) continue;
+            segs.push_back({(const uint8_t *)tensors[i].d_src, tensors[i].d_dst, tensors[i].blocks, tile});
+            tile += (tensors[i].blocks + tb - 1) / tb;
+        }
+        g.count = (uint32_t)segs.size() - g.first;
+        g.ntiles = tile;
+        b->groups.push_back(g);
+    }
+    if (!segs.empty()) {
+        if (!hip_ok(hipMalloc((void **)&b->d_seg, segs.size() * sizeof(Segment)), "hipMalloc") ||
+            !hip_ok(hipMemcpy(b->d_seg, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice),
+                    "hipMemcpy")) {
+            ggq_batch_destroy(b);
+            return GGQ_DEVICE;
+        }
+    }
+    *out = b;
+    return GGQ_OK;
+}
+
+ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
+    if (!b) return GGQ_INVALID;
+    hipStream_t st = (hipStream_t)hip_stream;
+    for (const auto &g : b->groups) {
+        ggq_status rc;
+        const Segment *seg = b->d_seg + g.first;
+        switch (b->out_ty) {
+        case GGQ_TYPE_F32: rc = launch_batch<OutF32>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
+        case GGQ_TYPE_F16: rc = launch_batch<OutF16>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
+        default: rc = launch_batch<OutBF16>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
+        }
+        if (rc != GGQ_OK) return rc;
+    }
+    for (const auto &p : b->plain) {
+        ggq_status rc = launch_out(p.ty, b->out_ty, p.dst, p.src, p.n, b->cus, st);
+        if (rc != GGQ_OK) return rc;
+    }
+    return GGQ_OK;
+}
+
+size_t ggq_batch_launches(const ggq_batch *b) { return b ? b->groups.size() + b->plain.size() : 0; }
+
+void ggq_batch_destroy(ggq_batch *b) {
+    if (!b) return;
+    if (b->d_seg) (void)hipFree(b->d_seg);
+    delete b;
+}
+
+// ---- streamed host -> device -------------------------------------------------------
+ggq_status ggq_ctx_create(int device, size_t staging_bytes, ggq_ctx **out) {
+    if (!out) return GGQ_INVALID;
+    int n = ggq_device_count();
+    if (device < 0 || device >= n) { g_err = "no such device"; return GGQ_DEVICE; }
+    if (staging_bytes < (1u << 20)) staging_bytes = 1u << 20;
+    size_t per_slot = (staging_bytes / ggq_ctx::SLOTS) & ~(size_t)4095;
+    return ctx_make(device, per_slot, 0, out);
+}
+
+ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *d_dst, size_t dst_elems,
+                                const void *h_src, size_t src_blocks) {
+    if (!c) return GGQ_INVALID;
+    ggq_status st = check_slice(ty, out_ty, dst_elems, src_blocks);
+    if (st != GGQ_OK) return st;
+    if (src_blocks == 0) return GGQ_OK;
+    if (!d_dst || !h_src) return GGQ_INVALID;
+    if ((uintptr_t)d_dst % 16 != 0) return GGQ_MISALIGNED;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(c->device));
+
+    const TypeInfo *ti = type_info(ty);
+    const size_t ob = out_bytes(out_ty);
+    // whole tiles per chunk (4096 elements) keep every chunk's output 16-byte aligned
+    size_t tile_blk = TILE_ELEMS / ti->elems;
+    size_t chunk_blocks = c->in_cap / ti->bytes / tile_blk * tile_blk;
+    if (chunk_blocks == 0) { (void)hipSetDevice(prev); return GGQ_INVALID; }
+    const uint8_t *s = (const uint8_t *)h_src;
+    uint8_t *d = (uint8_t *)d_dst;
+    ggq_status rc = GGQ_OK;
+    // find the slot that was used least recently: slots alternate, so continue
+    // from the first idle one
+    int slot = c->busy[0] && !c->busy[1] ? 1 : 0;
+    for (size_t done = 0; done < src_blocks && rc == GGQ_OK;) {
+        size_t nb = std::min(chunk_blocks, src_blocks - done);
+        if (c->busy[slot]) {
+            if (!hip_ok(hipEventSynchronize(c->done[slot]), "hipEventSynchronize")) { rc = GGQ_DEVICE; break; }
+            c->busy[slot] = false;
+        }
+        memcpy(c->h_in[slot], s + done * ti->bytes, nb * ti->bytes);
+        hipStream_t q = c->stream[slot];
+        if (!hip_ok(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], nb * ti->bytes, hipMemcpyHostToDevice, q), "H2D")) {
+            rc = GGQ_DEVICE;
+            break;
+        }
+        rc = launch_out(ty, out_ty, d + done * ti->elems * ob, c->d_in[slot], nb, c->cus, q);
+        if (rc != GGQ_OK) break;
+        if (!hip_ok(hipEventRecord(c->done[slot], q), "hipEventRecord")) { rc = GGQ_DEVICE; break; }
+        c->busy[slot] = true;
+        done += nb;
+        slot ^= 1;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+ggq_status ggq_sync(ggq_ctx *c) {
+    if (!c) return GGQ_INVALID;
+    for (int s = 0; s < ggq_ctx::SLOTS; ++s) {
+        HIP_TRY(hipStreamSynchronize(c->stream[s]));
+        c->busy[s] = false;
+    }
+    return GGQ_OK;
+}
+
+void ggq_ctx_destroy(ggq_ctx *c) {
+    if (!c) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(c->device);
+    ctx_free(c);
+    (void)hipSetDevice(prev);
+}
+
+}  // extern "C"

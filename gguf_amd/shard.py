@@ -1,0 +1,93 @@
+"""Index partition of a tensor table over the GPUs of one node.
+
+Blocks are independent, so whole-model conversion needs no exchange step: every
+rank derives the same partition from the same table and decodes only its share.
+No collective takes part in the data path.
+
+Rule: pieces are sorted by decoded size and dealt to the least-loaded rank
+(longest-processing-time first); a tensor whose decoded size exceeds a quarter
+of a rank's fair share is first cut into contiguous block ranges that end on row
+boundaries (a row = shape[0] elements, the contiguous dimension) -- the same way
+the reference plans output shards by accumulated tensor size
+(xtask/src/utils/write.rs:23-51), but with a balancing deal instead of a running
+cut, because here the shares run concurrently.
+"""
+from dataclasses import dataclass
+
+from .quants import block_bytes, block_elems
+
+
+@dataclass(frozen=True)
+class Piece:
+    tensor: int        # index into the table
+    name: str
+    ggml_type: int
+    block_begin: int   # first block of the tensor in this piece
+    blocks: int
+
+    @property
+    def elems(self):
+        return self.blocks * block_elems(self.ggml_type)
+
+    @property
+    def packed_bytes(self):
+        return self.blocks * block_bytes(self.ggml_type)
+
+
+def partition(items, world_size, row_elems=None, out_bytes=4):
+    """items: [(name, ggml_type, elements)]; returns a list of Piece lists, one per rank.
+
+    row_elems: optional list with each tensor's contiguous-dimension length, so that
+    cuts fall on row boundaries; default is one block per row (any block boundary).
+    """
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    cost = lambda ty, blocks: blocks * (block_elems(ty) * out_bytes + block_bytes(ty))
+    total = 0
+    table = []
+    for i, (name, ty, n) in enumerate(items):
+        be = block_elems(ty)
+        if be == 0:
+            raise ValueError(f"{name}: unsupported type {ty}")
+        if n % be:
+            raise ValueError(f"{name}: {n} elements is not a whole number of blocks")
+        row = row_elems[i] if row_elems else be
+        if row % be or n % row:
+            raise ValueError(f"{name}: row of {row} elements does not tile the tensor")
+        table.append((i, name, int(ty), n // be, row // be))
+        total += cost(ty, n // be)
+    limit = max(1, total // world_size // 4)
+
+    pieces = []
+    for i, name, ty, blocks, row_blocks in table:
+        c = cost(ty, blocks)
+        parts = 1 if world_size == 1 else min(-(-c // limit), blocks // row_blocks)
+        parts = max(1, parts)
+        rows = blocks // row_blocks
+        at = 0
+        for p in range(parts):
+            r = rows // parts + (1 if p < rows % parts else 0)
+            if r == 0:
+                continue
+            pieces.append(Piece(i, name, ty, at, r * row_blocks))
+            at += r * row_blocks
+        assert at == blocks
+
+    order = sorted(range(len(pieces)), key=lambda k: (-cost(pieces[k].ggml_type, pieces[k].blocks), k))
+    load = [0] * world_size
+    shares = [[] for _ in range(world_size)]
+    for k in order:
+        r = min(range(world_size), key=lambda j: (load[j], j))
+        shares[r].append(pieces[k])
+        load[r] += cost(pieces[k].ggml_type, pieces[k].blocks)
+    for s in shares:
+        s.sort(key=lambda p: (p.tensor, p.block_begin))
+    return shares
+
+
+def imbalance(shares, out_bytes=4):
+    """max rank load / mean rank load (1.0 = perfect)."""
+    loads = [sum(p.blocks * (block_elems(p.ggml_type) * out_bytes + block_bytes(p.ggml_type)) for p in s)
+             for s in shares]
+    mean = sum(loads) / len(loads)
+    return max(loads) / mean if mean else 1.0

@@ -1,0 +1,146 @@
+/*
+ * ggq.h -- C ABI of libggq: GGUF block dequantization on AMD MI355X (gfx950).
+ *
+ * The library replaces the per-block decode path of the reference crate
+ * `ggml-quants` (Rust, CPU) with hand-written HIP kernels.  Every entry point
+ * below names the reference interface it stands in for (paths relative to the
+ * reference checkout).  All signatures are plain C: pointers, sizes and u32
+ * type ids; no C++ or framework types cross this boundary.
+ *
+ * Type ids are the reference's `GGmlType` discriminants verbatim
+ * (ggus/src/tensor.rs:14-51): F32=0 F16=1 Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8
+ * Q8_1=9 Q2K=10 Q3K=11 Q4K=12 Q5K=13 Q6K=14 Q8K=15 IQ4NL=20 IQ4XS=23 BF16=30.
+ *
+ * There is no CPU fallback: without a usable HIP device every compute entry
+ * point returns GGQ_DEVICE.
+ */
+#ifndef GGQ_H
+#define GGQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces `QuantizeError` (ggml-quants/src/lib.rs:107-113) plus the cases the
+ * reference handles by panicking: `todo!()` bodies -> GGQ_UNSUPPORTED,
+ * `reslice` alignment panic (xtask/src/utils/operator/cast.rs:164-169) ->
+ * GGQ_MISALIGNED. */
+typedef enum ggq_status {
+    GGQ_OK = 0,
+    GGQ_INDIVISIBLE = 1,     /* QuantizeError::Indivisible    */
+    GGQ_LENGTH_MISMATCH = 2, /* QuantizeError::LengthMismatch */
+    GGQ_UNSUPPORTED = 3,     /* type id has no decoder (IQ1/IQ2/IQ3 codebook types, Q4_0_x_x, integers) */
+    GGQ_DEVICE = 4,          /* HIP runtime error or no device; see ggq_last_error() */
+    GGQ_MISALIGNED = 5,      /* device pointer alignment requirement not met */
+    GGQ_INVALID = 6          /* null pointer / bad argument */
+} ggq_status;
+
+enum {
+    GGQ_TYPE_F32 = 0, GGQ_TYPE_F16 = 1, GGQ_TYPE_Q4_0 = 2, GGQ_TYPE_Q4_1 = 3,
+    GGQ_TYPE_Q5_0 = 6, GGQ_TYPE_Q5_1 = 7, GGQ_TYPE_Q8_0 = 8, GGQ_TYPE_Q8_1 = 9,
+    GGQ_TYPE_Q2K = 10, GGQ_TYPE_Q3K = 11, GGQ_TYPE_Q4K = 12, GGQ_TYPE_Q5K = 13,
+    GGQ_TYPE_Q6K = 14, GGQ_TYPE_Q8K = 15, GGQ_TYPE_IQ4NL = 20, GGQ_TYPE_IQ4XS = 23,
+    GGQ_TYPE_BF16 = 30
+};
+
+/* ---- type table ---------------------------------------------------------
+ * Replaces `DataBlock::COUNT` (ggml-quants/src/lib.rs:11-21), `size_of` of the
+ * block structs as used by `GGmlType::size` (ggus/src/tensor.rs:102-144) and
+ * the layout names of ggml-quants/src/types.rs:10-33.
+ * Both return 0 for a type this library does not decode. */
+size_t ggq_block_elems(uint32_t ggml_type);
+size_t ggq_block_bytes(uint32_t ggml_type);
+/* Layout name as the reference prints it ("q40", "q4k", "iq4nl", ...,
+ * types.rs:35-62); NULL if unsupported. */
+const char *ggq_type_name(uint32_t ggml_type);
+/* Replaces `GGmlTypeSize::elements_to_bytes` (ggus/src/tensor.rs:83-96):
+ * shape[0] is the contiguous dimension and must be a multiple of the block
+ * size.  Returns GGQ_INDIVISIBLE where the reference asserts. */
+ggq_status ggq_elements_to_bytes(uint32_t ggml_type, const uint64_t *shape, size_t ndim,
+                                 uint64_t *bytes_out);
+
+const char *ggq_status_str(ggq_status st);
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char *ggq_last_error(void);
+/* Number of visible HIP devices (0 if the runtime is unusable). */
+int ggq_device_count(void);
+
+/* ---- dequantize, host buffers -------------------------------------------
+ * Replaces `<Blk as QuantExt<T, N>>::dequantize_slice(dst: &mut [T], src: &[Blk])`
+ * (ggml-quants/src/lib.rs:135-147).  `ggml_type` selects Blk, `out_type`
+ * selects T: F32 (0), F16 (1) or BF16 (30).  dst and src are HOST memory owned
+ * by the caller (typically an mmap window and a fresh anonymous mapping,
+ * xtask/src/utils/operator/cast.rs:150-161); any alignment is accepted.
+ * Checks run in the reference's order: dst_elems % N -> GGQ_INDIVISIBLE, then
+ * src_blocks != dst_elems / N -> GGQ_LENGTH_MISMATCH.
+ * Synchronous; runs on the calling thread's current HIP device through a
+ * per-thread pipeline of pinned staging buffers (H2D copy, decode kernel and
+ * D2H copy of consecutive chunks overlap on separate streams).  Safe to call
+ * from several threads at once, as the reference is from its writer threads
+ * (xtask/src/utils/write.rs:64-68). */
+ggq_status ggq_dequantize_slice(uint32_t ggml_type, uint32_t out_type,
+                                void *dst, size_t dst_elems,
+                                const void *src, size_t src_blocks);
+
+/* ---- dequantize, device-resident ----------------------------------------
+ * Same contract and checks as ggq_dequantize_slice, but d_dst and d_src are
+ * device pointers on the current device, and the kernel is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = default stream) without synchronizing.
+ * d_dst must be 16-byte aligned (GGQ_MISALIGNED otherwise); d_src may have any
+ * alignment.  No counterpart in the reference (it has no device memory); this
+ * is the form the hot path is benchmarked through. */
+ggq_status ggq_dequantize_device(uint32_t ggml_type, uint32_t out_type,
+                                 void *d_dst, size_t dst_elems,
+                                 const void *d_src, size_t src_blocks,
+                                 void *hip_stream);
+
+/* ---- dequantize, batch of device-resident tensors -------------------------
+ * One call decodes many tensors (a whole model's tensor table) with one kernel
+ * launch per block type present, instead of one per tensor.  Stands in for the
+ * loop over tensors that the reference's cast operator performs
+ * (xtask/src/utils/operator/cast.rs:73-90), each iteration of which ends in
+ * dequantize_slice. */
+typedef struct ggq_tensor {
+    uint32_t ggml_type;   /* block type of src                      */
+    uint32_t reserved;    /* must be 0                              */
+    const void *d_src;    /* device pointer, packed blocks          */
+    void *d_dst;          /* device pointer, 16-byte aligned        */
+    uint64_t blocks;      /* number of blocks in d_src              */
+} ggq_tensor;
+
+typedef struct ggq_batch ggq_batch;
+
+/* Validates the table, builds and uploads the launch plan (allocates a small
+ * device table).  The plan can be run any number of times. */
+ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t out_type,
+                            ggq_batch **out);
+/* Enqueues the plan's kernels on `hip_stream`; does not synchronize. */
+ggq_status ggq_batch_run(ggq_batch *batch, void *hip_stream);
+/* Kernel launches one run issues (for measurement bookkeeping). */
+size_t ggq_batch_launches(const ggq_batch *batch);
+void ggq_batch_destroy(ggq_batch *batch);
+
+/* ---- streamed host -> device decode ---------------------------------------
+ * A context owns pinned staging memory, device staging and two HIP streams on
+ * one device.  ggq_dequantize_async copies packed blocks from host memory
+ * (pageable or pinned) in chunks and decodes each chunk on the device as soon
+ * as it lands, copy and decode overlapping; the decoded tensor stays in device
+ * memory at d_dst.  The call returns once the last chunk has been staged;
+ * ggq_sync waits for everything enqueued.  No counterpart in the reference;
+ * this is the whole-model conversion path (one context per GPU, tensors dealt
+ * to GPUs by an index partition). */
+typedef struct ggq_ctx ggq_ctx;
+ggq_status ggq_ctx_create(int device, size_t staging_bytes, ggq_ctx **out);
+ggq_status ggq_dequantize_async(ggq_ctx *ctx, uint32_t ggml_type, uint32_t out_type,
+                                void *d_dst, size_t dst_elems,
+                                const void *h_src, size_t src_blocks);
+ggq_status ggq_sync(ggq_ctx *ctx);
+void ggq_ctx_destroy(ggq_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGQ_H */

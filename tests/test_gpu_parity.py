@@ -1,0 +1,237 @@
+"""Parity of the HIP kernels with the CPU oracle, through the C ABI.
+
+Bar: bit-exact for every finite result (the unpack is integer work and every float
+step is a single IEEE operation on both sides); a NaN must be a NaN on both sides
+(payloads are not compared: x86 and the GPU pick different default NaNs for inf*0).
+f16 / bf16 outputs: bit-exact as well (tolerance 0 ULP, tighter than the 1 ULP
+the target statement allows).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import same_bits, same_bits16, first_diff
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+BLOCK_TYPES = [2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 20, 23]
+ALL_TYPES = BLOCK_TYPES + [1, 30]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+def gpu_decode(torch, ty, packed, out="f32", offset=0):
+    """Decode on the device; `offset` shifts the source pointer to test misaligned inputs."""
+    import gguf_amd as g
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out]
+    n = packed.size // g.block_bytes(ty) * g.block_elems(ty)
+    buf = torch.empty(packed.size + offset + 64, dtype=torch.uint8, device="cuda")
+    src = buf[offset:offset + packed.size]
+    src.copy_(torch.from_numpy(packed))
+    dst = torch.empty(n, dtype=dt, device="cuda")
+    g.dequantize_slice(ty, dst, src)
+    torch.cuda.synchronize()
+    if out == "f32":
+        return dst.cpu().numpy()
+    return dst.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def check(oracle, ty, packed, got, out):
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    want = oracle.dequantize(ty, packed, o_out, threads=8)
+    if out == "f32":
+        assert same_bits(got, want), first_diff(got, want)
+    else:
+        assert same_bits16(got, want, out), first_diff(got, want)
+
+
+@pytest.mark.parametrize("ty", ALL_TYPES)
+def test_seeded_golden(torch_cuda, oracle, ty):
+    s = np.load(os.path.join(G, "seeded.npz"))
+    p = s[f"t{ty}_packed"]
+    assert same_bits(gpu_decode(torch_cuda, ty, p), s[f"t{ty}_f32"])
+    assert same_bits16(gpu_decode(torch_cuda, ty, p, "f16"), s[f"t{ty}_f16"], "f16")
+    assert same_bits16(gpu_decode(torch_cuda, ty, p, "bf16"), s[f"t{ty}_bf16"], "bf16")
+
+
+@pytest.mark.parametrize("ty", BLOCK_TYPES)
+def test_kat_and_edge_scales(torch_cuda, oracle, ty):
+    k = np.load(os.path.join(G, "kat.npz"))
+    got = gpu_decode(torch_cuda, ty, k[f"t{ty}_packed"])
+    assert same_bits(got, k[f"t{ty}_f32"]), first_diff(got, k[f"t{ty}_f32"])
+    e = np.load(os.path.join(G, "edges.npz"))
+    got = gpu_decode(torch_cuda, ty, e[f"t{ty}_packed"])
+    assert same_bits(got, e[f"t{ty}_f32"]), first_diff(got, e[f"t{ty}_f32"])
+    got = gpu_decode(torch_cuda, ty, e[f"t{ty}_packed"], "f16")
+    assert same_bits16(got, e[f"t{ty}_f16"], "f16")
+
+
+# block counts around the tile size (16 K-blocks / 128 legacy blocks per wave tile),
+# one block, and enough tiles that waves loop
+def counts_for(n):
+    tb = 4096 // n
+    return [1, 2, tb - 1, tb, tb + 1, 3 * tb + 5, 40 * tb + 7]
+
+
+@pytest.mark.parametrize("ty", BLOCK_TYPES)
+@pytest.mark.parametrize("out", ["f32", "f16", "bf16"])
+def test_ragged_sizes(torch_cuda, oracle, ty, out):
+    from gguf_amd import synth
+    for blocks in counts_for(oracle.block_elems(ty)):
+        p = synth.random_blocks(ty, blocks, 9000 + blocks)
+        check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, out), out)
+
+
+@pytest.mark.parametrize("ty", BLOCK_TYPES)
+def test_adversarial_bytes(torch_cuda, oracle, ty):
+    from gguf_amd import synth
+    p = synth.random_blocks(ty, 3000, 31337 + ty, adversarial=True)
+    for out in ("f32", "f16", "bf16"):
+        check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, out), out)
+
+
+@pytest.mark.parametrize("ty", BLOCK_TYPES)
+@pytest.mark.parametrize("offset", [2, 4, 6, 8, 10, 1, 15])
+def test_source_alignment(torch_cuda, oracle, ty, offset):
+    """Blocks are only 2-byte aligned in the reference (f16 header); any byte offset must decode."""
+    from gguf_amd import synth
+    blocks = 5 * (4096 // oracle.block_elems(ty)) + 3
+    p = synth.random_blocks(ty, blocks, 555 + offset)
+    check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, "f32", offset), "f32")
+
+
+@pytest.mark.parametrize("ty", [1, 30])
+@pytest.mark.parametrize("out", ["f32", "f16", "bf16"])
+def test_widen_all_patterns(torch_cuda, oracle, ty, out):
+    bits = np.arange(65536, dtype=np.uint16)
+    for n, off in ((65536, 0), (65533, 0), (1001, 2), (7, 0), (65536, 6)):
+        p = bits[:n].view(np.uint8)
+        check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, out, off), out)
+
+
+def test_slice_errors_on_device(torch_cuda):
+    """lib.rs:293-338 through the device entry point."""
+    import gguf_amd as g
+    t = torch_cuda
+    src = t.zeros(34 * 3, dtype=t.uint8, device="cuda")
+    dst = t.zeros(96, dtype=t.float32, device="cuda")
+    with pytest.raises(g.Indivisible):
+        g.Q8_0.dequantize_slice(dst[:31], src[:34])
+    with pytest.raises(g.LengthMismatch):
+        g.Q8_0.dequantize_slice(dst[:64], src)
+    with pytest.raises(g.Indivisible):
+        g.Q8_0.dequantize_slice(dst[:31], src)
+    with pytest.raises(g.Misaligned):
+        g.Q8_0.dequantize_slice(dst[1:33], src[:34])
+    dst.fill_(7.0)
+    g.Q8_0.dequantize_slice(dst, src)          # zero blocks -> exact +0.0
+    t.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), np.zeros(96, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("ty", [8, 2, 12, 14, 1])
+def test_host_buffer_entry_point(torch_cuda, oracle, ty):
+    """ggq_dequantize_slice: host pointers in and out, odd host alignment, several chunks."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    n = oracle.block_elems(ty)
+    blocks = (9 << 20) // n + 3            # > 2 staged chunks of 4 Mi elements
+    p = synth.random_blocks(ty, blocks, 4242)
+    hold = np.zeros(p.size + 3, dtype=np.uint8)
+    hold[3:] = p                            # misaligned host source
+    dst = np.full(blocks * n + 1, 9.0, dtype=np.float32)
+    g.dequantize_slice(ty, dst[1:], hold[3:])
+    want = oracle.dequantize(ty, p, threads=8)
+    assert same_bits(dst[1:], want), first_diff(dst[1:], want)
+    assert dst[0] == 9.0
+
+
+def test_batch_matches_single(torch_cuda, oracle):
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    specs = [(12, 700), (14, 33), (12, 1), (2, 5000), (14, 260), (12, 16), (8, 129), (1, 5001), (23, 40)]
+    tensors, packed = [], []
+    for i, (ty, blocks) in enumerate(specs):
+        p = synth.random_blocks(ty, blocks, 800 + i)
+        pad = (i * 2) % 16                  # different source alignments inside one launch
+        buf = t.empty(p.size + pad, dtype=t.uint8, device="cuda")
+        src = buf[pad:]
+        src.copy_(t.from_numpy(p))
+        dst = t.empty(blocks * oracle.block_elems(ty), dtype=t.float32, device="cuda")
+        tensors.append((ty, src, dst))
+        packed.append(p)
+    b = g.Batch(tensors)
+    assert b.launches == 6                  # one per block type present (Q4K, Q6K, Q4_0, Q8_0, IQ4XS) + the f16 tensor
+    for _ in range(2):
+        for _, _, d in tensors:
+            d.fill_(-1.0)
+        b.run()
+        t.cuda.synchronize()
+        for (ty, _, d), p in zip(tensors, packed):
+            want = oracle.dequantize(ty, p, threads=8)
+            assert same_bits(d.cpu().numpy(), want), (ty, first_diff(d.cpu().numpy(), want))
+    b.close()
+
+
+def test_streamed_context(torch_cuda, oracle):
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    ctx = g.Context(0, staging_bytes=2 << 20)     # small staging -> many chunks
+    work = []
+    for i, (ty, blocks) in enumerate([(12, 20000), (14, 9000), (2, 70000), (30, 300001)]):
+        p = synth.random_blocks(ty, blocks, 600 + i)
+        dst = t.empty(blocks * oracle.block_elems(ty), dtype=t.float32, device="cuda")
+        ctx.dequantize_async(ty, dst, p)
+        work.append((ty, p, dst))
+    ctx.sync()
+    for ty, p, dst in work:
+        want = oracle.dequantize(ty, p, threads=8)
+        assert same_bits(dst.cpu().numpy(), want), (ty, first_diff(dst.cpu().numpy(), want))
+    ctx.close()
+
+
+def test_q4_0_4096_square(torch_cuda, oracle):
+    """BASELINE config: a single 4096 x 4096 Q4_0 tensor, packed by the reference's quantizer rule."""
+    rng = np.random.default_rng(0xC0FFEE02)
+    x = (rng.standard_normal(4096 * 4096) * 0.02).astype(np.float32)
+    p = oracle.quantize(2, x)
+    assert p.size == 9_437_184
+    got = gpu_decode(torch_cuda, 2, p)
+    want = oracle.dequantize(2, p, threads=8)
+    assert same_bits(got, want)
+    assert float(np.max(np.abs(got - x))) < 8e-2        # the reference's own tolerance (q4_0.rs:62)
+
+
+def test_full_size_properties(torch_cuda, oracle):
+    """At benchmark size the oracle is too slow to decode everything; check instead
+    (a) a sampled set of blocks bit-for-bit, (b) the decode is a pure function of the
+    block: decoding a permutation of the blocks gives the permuted output."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    for ty in (12, 14):
+        bb, n = g.block_bytes(ty), g.block_elems(ty)
+        blocks = 4096 * 11008 // n                      # one 7B FFN matrix
+        src = synth.random_blocks_device(ty, blocks, 77, "cuda")
+        dst = t.empty(blocks * n, dtype=t.float32, device="cuda")
+        g.dequantize_slice(ty, dst, src)
+        perm = t.randperm(blocks, device="cuda")
+        src2 = src.view(blocks, bb)[perm].contiguous().view(-1)
+        dst2 = t.empty_like(dst)
+        g.dequantize_slice(ty, dst2, src2)
+        t.cuda.synchronize()
+        assert t.equal(dst.view(blocks, n)[perm].view(t.int32), dst2.view(blocks, n).view(t.int32))
+        idx = t.randint(0, blocks, (4096,), device="cuda")
+        sample = src.view(blocks, bb)[idx].cpu().numpy().reshape(-1)
+        want = oracle.dequantize(ty, sample, threads=8)
+        got = dst.view(blocks, n)[idx].cpu().numpy().reshape(-1)
+        assert same_bits(got, want)
