@@ -7,6 +7,13 @@ wrappers in gguf_amd.quants turn into DeviceError.
 import ctypes
 import os
 
+# torch must be loaded first.  libggq.so needs libamdhip64.so.7; PyTorch ships its
+# own copy of that runtime.  The dynamic linker binds libggq to whichever copy is
+# already in the process, and the two must be ONE runtime, or torch's device pointers
+# and streams mean nothing to the kernels here (a second runtime in the process
+# does not even see the GPU).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libggq.so")
 

@@ -215,16 +215,17 @@ struct Q3K {
 };
 
 // 6-bit (scale, min) pair `is` of 8 from the 12 packed bytes at s (Q4_K, Q5_K)
+// Branch-free: with j = is & 3, the three bytes A = s[j], B = s[j+4], C = s[j+8]
+// hold everything either case needs (is < 4: sc = A & 63, mn = B & 63;
+// is >= 4: sc = (C & 15) | (A >> 6) << 4, mn = (C >> 4) | (B >> 6) << 4), so lanes
+// of one wave that sit in different sub-blocks never diverge.
 template <class R>
 __device__ __forceinline__ void scale_min_k4(const R &r, uint32_t s, uint32_t is, uint32_t &sc, uint32_t &mn) {
-    if (is < 4) {
-        sc = r.u8(s + is) & 63u;
-        mn = r.u8(s + is + 4) & 63u;
-    } else {
-        uint32_t t = r.u8(s + is + 4);
-        sc = (t & 0xFu) | ((r.u8(s + is - 4) >> 6) << 4);
-        mn = (t >> 4) | ((r.u8(s + is) >> 6) << 4);
-    }
+    uint32_t j = is & 3u;
+    uint32_t A = r.u8(s + j), B = r.u8(s + j + 4), C = r.u8(s + j + 8);
+    bool low = is < 4;
+    sc = low ? (A & 63u) : ((C & 0xFu) | ((A >> 6) << 4));
+    mn = low ? (B & 63u) : ((C >> 4) | ((B >> 6) << 4));
 }
 
 // layout ggml-quants/src/structs/q4_k.rs:6-13   d:f16 | dmin:f16 | scales[12] | qs[128]

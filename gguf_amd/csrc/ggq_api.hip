@@ -95,13 +95,17 @@ ggq_status dev_info(int dev, DevInfo &out) {
     return GGQ_OK;
 }
 
-// Workgroups for `ntiles` wave tiles: one wave per tile until the chip is full
-// (8 workgroups of 4 waves per CU), then waves walk several tiles each.
-uint32_t grid_for(uint64_t ntiles, int cus) {
-    uint64_t wgs = (ntiles + WAVES_PER_WG - 1) / WAVES_PER_WG;
-    uint64_t cap = (uint64_t)cus * 8;
-    return (uint32_t)std::max<uint64_t>(1, std::min(wgs, cap));
+// Host-side tile geometry, the same numbers as TileGeom<F, O> in kernels.h.
+struct HostGeom {
+    uint64_t elems, blocks, bytes;   // per tile: output elements, blocks, packed bytes
+};
+HostGeom host_geom(const TypeInfo *ti, uint32_t out_ty) {
+    uint64_t epl = out_ty == GGQ_TYPE_F32 ? 4 : 8;
+    uint64_t elems = (uint64_t)WG_THREADS * epl * STORES_PER_THREAD;
+    return {elems, elems / ti->elems, elems / ti->elems * ti->bytes};
 }
+// gridDim.x limit kept well below 2^31; larger tensors take several launches
+constexpr uint64_t kMaxGrid = 1u << 30;
 
 #define GGQ_FORMATS(X)                                                                      \
     X(GGQ_TYPE_Q4_0, Q4_0) X(GGQ_TYPE_Q4_1, Q4_1) X(GGQ_TYPE_Q5_0, Q5_0) X(GGQ_TYPE_Q5_1, Q5_1) \
@@ -111,14 +115,18 @@ uint32_t grid_for(uint64_t ntiles, int cus) {
 
 // ---- single tensor --------------------------------------------------------------
 template <class O>
-ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t blocks, int cus,
-                         hipStream_t st) {
+ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t blocks, hipStream_t st) {
     switch (ty) {
 #define X(ID, F)                                                                              \
     case ID: {                                                                                \
-        uint64_t ntiles = (blocks + TileGeom<F>::TB - 1) / TileGeom<F>::TB;                   \
-        hipLaunchKernelGGL((deq_tiles<F, O, kNT>), dim3(grid_for(ntiles, cus)), dim3(WG_THREADS), \
-                           0, st, (const uint8_t *)d_src, (typename O::T *)d_dst, blocks);    \
+        typedef TileGeom<F, O> G;                                                             \
+        const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;                                 \
+        for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                  \
+            uint64_t n = std::min(kMaxGrid, ntiles - t0);                                     \
+            hipLaunchKernelGGL((deq_one<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
+                               (const uint8_t *)d_src + t0 * G::TBYTES,                       \
+                               (typename O::T *)d_dst + t0 * G::ELEMS, blocks - t0 * G::TB);  \
+        }                                                                                     \
         break;                                                                                \
     }
         GGQ_FORMATS(X)
@@ -134,12 +142,12 @@ template <bool BF16SRC, class O>
 ggq_status launch_widen(void *d_dst, const void *d_src, uint64_t n, int cus, hipStream_t st) {
     typedef typename O::T T;
     const bool fast = ((uintptr_t)d_src % 8 == 0);
-    uint64_t n4 = fast ? n / 4 : 0;
-    if (n4) {
-        uint64_t wgs = (n4 + WG_THREADS - 1) / WG_THREADS;
-        uint32_t grid = (uint32_t)std::min<uint64_t>(wgs, (uint64_t)cus * 8);
-        hipLaunchKernelGGL((widen_vec<BF16SRC, O, kNT>), dim3(grid), dim3(WG_THREADS), 0, st,
-                           (const uint2 *)d_src, (T *)d_dst, n4);
+    const uint64_t n4 = fast ? n / 4 : 0;
+    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+    for (uint64_t i0 = 0; i0 < n4; i0 += kMaxGrid * per_wg) {
+        uint64_t cnt = std::min(kMaxGrid * per_wg, n4 - i0);
+        hipLaunchKernelGGL((widen_vec<BF16SRC, O, kNT>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)),
+                           dim3(WG_THREADS), 0, st, (const uint2v *)d_src + i0, (T *)d_dst + 4 * i0, cnt);
     }
     if (n4 * 4 < n) {
         uint64_t restn = n - n4 * 4;
@@ -158,7 +166,7 @@ ggq_status launch_any(uint32_t ty, void *d_dst, const void *d_src, uint64_t bloc
     if (blocks == 0) return GGQ_OK;
     if (ty == GGQ_TYPE_F16) return launch_widen<false, O>(d_dst, d_src, blocks, cus, st);
     if (ty == GGQ_TYPE_BF16) return launch_widen<true, O>(d_dst, d_src, blocks, cus, st);
-    return launch_blocks<O>(ty, d_dst, d_src, blocks, cus, st);
+    return launch_blocks<O>(ty, d_dst, d_src, blocks, st);
 }
 
 ggq_status launch_out(uint32_t ty, uint32_t out_ty, void *d_dst, const void *d_src, uint64_t blocks,
@@ -173,13 +181,15 @@ ggq_status launch_out(uint32_t ty, uint32_t out_ty, void *d_dst, const void *d_s
 
 // ---- batch ------------------------------------------------------------------------
 template <class O>
-ggq_status launch_batch(uint32_t ty, const Segment *d_seg, uint32_t nseg, uint64_t ntiles, int cus,
-                        hipStream_t st) {
+ggq_status launch_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hipStream_t st) {
     switch (ty) {
 #define X(ID, F)                                                                                 \
     case ID:                                                                                     \
-        hipLaunchKernelGGL((deq_tiles_batch<F, O, kNT>), dim3(grid_for(ntiles, cus)),            \
-                           dim3(WG_THREADS), 0, st, d_seg, nseg, ntiles);                        \
+        for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                     \
+            uint64_t n = std::min(kMaxGrid, ntiles - t0);                                        \
+            hipLaunchKernelGGL((deq_batch<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
+                               d_table + t0, n);                                                 \
+        }                                                                                        \
         break;
         GGQ_FORMATS(X)
 #undef X
@@ -190,16 +200,6 @@ ggq_status launch_batch(uint32_t ty, const Segment *d_seg, uint32_t nseg, uint64
     return GGQ_OK;
 }
 
-uint32_t tile_blocks(uint32_t ty) {
-    switch (ty) {
-#define X(ID, F) \
-    case ID: return TileGeom<F>::TB;
-        GGQ_FORMATS(X)
-#undef X
-    default: return 0;
-    }
-}
-
 }  // namespace
 
 struct ggq_batch {
@@ -208,8 +208,7 @@ struct ggq_batch {
     uint32_t out_ty = 0;
     struct Group {
         uint32_t ty;
-        uint32_t first, count;   // range in the device segment table
-        uint64_t ntiles;
+        uint64_t first, ntiles;   // range in the device tile table
     };
     std::vector<Group> groups;
     // F16 / BF16 tensors are widened one launch each
@@ -220,7 +219,7 @@ struct ggq_batch {
         uint64_t n;
     };
     std::vector<Plain> plain;
-    Segment *d_seg = nullptr;
+    TileRef *d_table = nullptr;
 };
 
 // ---- pinned staging pipeline (host-buffer entry point and ggq_ctx) ----------------
@@ -410,7 +409,8 @@ ggq_status ggq_dequantize_slice(uint32_t ty, uint32_t out_ty, void *dst, size_t 
 
     const TypeInfo *ti = type_info(ty);
     const size_t ob = out_bytes(out_ty);
-    // blocks per chunk: whole tiles, so every chunk's output offset stays 16-byte aligned
+    // 4 Mi elements per chunk: a multiple of every tile size, so each chunk's
+    // output offset stays 16-byte aligned
     size_t chunk_blocks = kHostChunkElems / ti->elems;
     const uint8_t *s = (const uint8_t *)src;
     uint8_t *d = (uint8_t *)dst;
@@ -486,23 +486,29 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
         }
         if (std::find(types.begin(), types.end(), ty) == types.end()) types.push_back(ty);
     }
-    std::vector<Segment> segs;
+    // one TileRef per tile, tensors of one type consecutive (caller's order inside a type)
+    std::vector<TileRef> table;
+    const uint64_t ob = out_bytes(out_ty);
     for (uint32_t ty : types) {
-        ggq_batch::Group g{ty, (uint32_t)segs.size(), 0, 0};
-        uint32_t tb = tile_blocks(ty);
-        uint64_t tile = 0;
+        const TypeInfo *ti = type_info(ty);
+        const HostGeom hg = host_geom(ti, out_ty);
+        ggq_batch::Group g{ty, table.size(), 0};
         for (size_t i = 0; i < count; ++i) {
             if (tensors[i].ggml_type != ty || tensors[i].blocks == 0) continue;
-            segs.push_back({(const uint8_t *)tensors[i].d_src, tensors[i].d_dst, tensors[i].blocks, tile});
-            tile += (tensors[i].blocks + tb - 1) / tb;
+            const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
+            if (src >> 48) { ggq_batch_destroy(b); return GGQ_INVALID; }
+            const uint64_t nt = (tensors[i].blocks + hg.blocks - 1) / hg.blocks;
+            for (uint64_t t = 0; t < nt; ++t) {
+                uint64_t nblk = std::min<uint64_t>(hg.blocks, tensors[i].blocks - t * hg.blocks);
+                table.push_back({(src + t * hg.bytes) | (nblk << 48), dst + t * hg.elems * ob});
+            }
         }
-        g.count = (uint32_t)segs.size() - g.first;
-        g.ntiles = tile;
+        g.ntiles = table.size() - g.first;
         b->groups.push_back(g);
     }
-    if (!segs.empty()) {
-        if (!hip_ok(hipMalloc((void **)&b->d_seg, segs.size() * sizeof(Segment)), "hipMalloc") ||
-            !hip_ok(hipMemcpy(b->d_seg, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice),
+    if (!table.empty()) {
+        if (!hip_ok(hipMalloc((void **)&b->d_table, table.size() * sizeof(TileRef)), "hipMalloc") ||
+            !hip_ok(hipMemcpy(b->d_table, table.data(), table.size() * sizeof(TileRef), hipMemcpyHostToDevice),
                     "hipMemcpy")) {
             ggq_batch_destroy(b);
             return GGQ_DEVICE;
@@ -517,11 +523,11 @@ ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     for (const auto &g : b->groups) {
         ggq_status rc;
-        const Segment *seg = b->d_seg + g.first;
+        const TileRef *tab = b->d_table + g.first;
         switch (b->out_ty) {
-        case GGQ_TYPE_F32: rc = launch_batch<OutF32>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
-        case GGQ_TYPE_F16: rc = launch_batch<OutF16>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
-        default: rc = launch_batch<OutBF16>(g.ty, seg, g.count, g.ntiles, b->cus, st); break;
+        case GGQ_TYPE_F32: rc = launch_batch<OutF32>(g.ty, tab, g.ntiles, st); break;
+        case GGQ_TYPE_F16: rc = launch_batch<OutF16>(g.ty, tab, g.ntiles, st); break;
+        default: rc = launch_batch<OutBF16>(g.ty, tab, g.ntiles, st); break;
         }
         if (rc != GGQ_OK) return rc;
     }
@@ -536,7 +542,7 @@ size_t ggq_batch_launches(const ggq_batch *b) { return b ? b->groups.size() + b-
 
 void ggq_batch_destroy(ggq_batch *b) {
     if (!b) return;
-    if (b->d_seg) (void)hipFree(b->d_seg);
+    if (b->d_table) (void)hipFree(b->d_table);
     delete b;
 }
 
@@ -564,8 +570,9 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
 
     const TypeInfo *ti = type_info(ty);
     const size_t ob = out_bytes(out_ty);
-    // whole tiles per chunk (4096 elements) keep every chunk's output 16-byte aligned
-    size_t tile_blk = TILE_ELEMS / ti->elems;
+    // chunks are whole tiles of either output width (8192 elements), so every
+    // chunk's output offset stays 16-byte aligned
+    size_t tile_blk = 8192 / ti->elems;
     size_t chunk_blocks = c->in_cap / ti->bytes / tile_blk * tile_blk;
     if (chunk_blocks == 0) { (void)hipSetDevice(prev); return GGQ_INVALID; }
     const uint8_t *s = (const uint8_t *)h_src;

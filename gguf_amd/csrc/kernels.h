@@ -1,23 +1,10 @@
 // kernels.h -- dequantize kernels for gfx950 (MI355X).
 //
-// Work decomposition ("wave tiles").  The unit of work is a tile of
-// TILE_ELEMS = 4096 output elements (16 K-quant blocks or 128 legacy blocks),
-// owned by ONE 64-lane wave:
-//   1. the wave copies the tile's packed bytes HBM -> registers with aligned
-//      16-byte loads (consecutive lanes, consecutive 16-byte slots; the source
-//      pointer may have any alignment, the slots are those of the enclosing
-//      16-byte grid), then registers -> its private LDS slice;
-//   2. the loads for the wave's NEXT tile are issued before decoding starts,
-//      so their HBM latency hides under the decode and the stores;
-//   3. each lane decodes EPL consecutive elements per step straight from LDS
-//      (bit unpack, per-sub-block scale) and stores 16 bytes; the 64 lanes of a
-//      step write one contiguous 1 KiB run, so every store instruction is a
-//      fully coalesced burst of 8 whole 128-byte lines.
-// No workgroup barrier is needed: a wave only reads LDS bytes it wrote itself,
-// and the LDS executes one wave's instructions in order.
-//
-// The kernel is bound by HBM traffic (about 88 % of it the output stores), not
-// by arithmetic: there is no matrix work here.
+// The work is a pure memory stream: 0.33-1.1 bytes read and 2-4 bytes written per
+// element, a handful of integer and float operations in between, no reuse and no
+// matrix work.  Everything here serves the one thing that decides the speed: the
+// order and shape in which bytes reach HBM.  TileGeom / deq_tile below give the
+// decomposition and the measurements behind each choice.
 #pragma once
 #include "formats.h"
 
@@ -25,15 +12,12 @@ namespace ggq {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
-
-constexpr uint32_t TILE_ELEMS = 4096;
-constexpr uint32_t WAVES_PER_WG = 4;
-constexpr uint32_t WG_THREADS = 64 * WAVES_PER_WG;
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
 
 // ---- output element types ---------------------------------------------------
 struct OutF32 {
     typedef float T;
-    static constexpr uint32_t EPL = 4;   // elements per lane per step (16 bytes)
+    static constexpr uint32_t EPL = 4;   // elements per lane per store (16 bytes)
     template <bool NT>
     static __device__ __forceinline__ void store(T *p, const float (&a)[4]) {
         float4v v = {a[0], a[1], a[2], a[3]};
@@ -47,6 +31,10 @@ struct OutF16 {
     typedef uint16_t T;
     static constexpr uint32_t EPL = 8;
     static __device__ __forceinline__ uint32_t pk(float a, float b) {
+        // The empty asm keeps the f32 value opaque.  Without it hipcc folds the
+        // producing multiply into the conversion as v_fma_mixlo_f16(x, y, +0), and
+        // (-0) + (+0) = +0 loses the sign of a negative zero product.
+        asm volatile("" : "+v"(a), "+v"(b));
         return (uint32_t)__half_as_ushort(__float2half_rn(a)) |
                ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
     }
@@ -62,6 +50,7 @@ struct OutBF16 {
     typedef uint16_t T;
     static constexpr uint32_t EPL = 8;
     static __device__ __forceinline__ uint32_t pk(float a, float b) {
+        asm volatile("" : "+v"(a), "+v"(b));   // same reason as OutF16::pk
         __bf16 x = (__bf16)a, y = (__bf16)b;
         return (uint32_t)__builtin_bit_cast(unsigned short, x) |
                ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
@@ -74,59 +63,74 @@ struct OutBF16 {
     }
 };
 
-// One tensor (or contiguous block range) of a batch.  tile_begin is the index
-// of its first tile in the batch-wide tile numbering.
-struct Segment {
-    const uint8_t *src;   // packed blocks, any alignment
-    void *dst;            // 16-byte aligned
-    uint64_t blocks;
-    uint64_t tile_begin;
-};
+// ---- tile shape ----------------------------------------------------------------
+// A workgroup of 512 threads owns one tile and every thread issues exactly two
+// 16-byte stores: 4096 elements (16 KiB) for f32 output, 8192 elements (16 KiB) for
+// f16 / bf16 output.  Measured on MI355X: one store per thread is bound by workgroup
+// launch rate, four or more stretch the window of addresses being written at any
+// moment and cost DRAM efficiency; two is the optimum.
+constexpr uint32_t WG_THREADS = 512;
+constexpr uint32_t STORES_PER_THREAD = 2;
+// Distance, in workgroups, of the L2 prefetch (see deq_tile).  A multiple of 8:
+// workgroups b and b + 8k run on the same XCD, so the line lands in the L2 that the
+// later workgroup will read.  About one full chip's worth of resident workgroups.
+constexpr uint32_t PREFETCH_TILES = 2048;
 
-template <class F>
+template <class F, class O>
 struct TileGeom {
-    static constexpr uint32_t TB = TILE_ELEMS / F::N;         // blocks per tile
-    static constexpr uint32_t TBYTES = TB * F::BYTES;         // packed bytes per tile
-    static constexpr uint32_t SLOTS = TBYTES / 16 + 1;        // 16-byte slots a tile can touch
-    static constexpr uint32_t LDS_SLOTS = SLOTS + 1;          // + slack for the funnel read
-    static constexpr uint32_t LPL = (SLOTS + 63) / 64;        // loads per lane
-    static_assert(TBYTES % 16 == 0, "tile bytes must be whole slots");
+    static constexpr uint32_t ELEMS = WG_THREADS * O::EPL * STORES_PER_THREAD;
+    static constexpr uint32_t TB = ELEMS / F::N;               // blocks per tile
+    static constexpr uint32_t TBYTES = TB * F::BYTES;          // packed bytes per tile
+    static constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1;  // 16-byte slots a tile can touch
+    static constexpr uint32_t LDS_SLOTS = SLOTS + 1;           // + slack for the funnel read
+    static constexpr uint32_t LPT = (SLOTS + WG_THREADS - 1) / WG_THREADS;   // loads per thread
+    static_assert(ELEMS % F::N == 0, "a tile is a whole number of blocks");
 };
 
-// Issue the aligned 16-byte loads of one tile into registers.
-//   base16 : source pointer rounded down to 16 bytes
-//   slot0  : first slot of the tile, nslots : slots that hold tile bytes
-template <class F>
-__device__ __forceinline__ void tile_fetch(uint4v (&reg)[TileGeom<F>::LPL], const uint4v *base16,
-                                           uint64_t slot0, uint32_t nslots, uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 0; k < TileGeom<F>::LPL; ++k) {
-        uint32_t s = lane + 64 * k;
-        if (s < nslots) reg[k] = __builtin_nontemporal_load(base16 + slot0 + s);
-    }
-}
+// One tile of a batch: everything a workgroup needs, in one 16-byte record, so
+// the lookup is a single scalar load with nothing depending on an earlier load.
+struct TileRef {
+    uint64_t src_nblk;   // bits 0..47 address of the tile's first block, bits 48..63 blocks in the tile
+    uint64_t dst;        // address of the tile's first output element (16-byte aligned)
+};
 
-template <class F>
-__device__ __forceinline__ void tile_stage(uint4v *lds, const uint4v (&reg)[TileGeom<F>::LPL],
-                                           uint32_t nslots, uint32_t lane) {
-#pragma unroll
-    for (uint32_t k = 0; k < TileGeom<F>::LPL; ++k) {
-        uint32_t s = lane + 64 * k;
-        if (s < nslots) lds[s] = reg[k];
-    }
-}
-
-// Decode one staged tile and store it.  `nblk` = blocks of the tile that exist
-// (TB except for a tensor's last tile), off0 = byte offset of the tile's first
-// block inside the LDS image (0..15).
+// Decode one tile.
+//   src   first block of the tile (any alignment), nblk blocks present (<= TB)
+//   out   first output element of the tile (16-byte aligned)
+//   pf    packed bytes of the tile PREFETCH_TILES workgroups ahead, or null
+// Steps: (1) aligned 16-byte loads of the packed bytes into LDS, consecutive
+// threads -> consecutive 16-byte slots of the enclosing 16-byte grid; (2) one dword
+// per 128-byte line of the far-ahead tile is loaded and never used: it only pulls
+// those lines into this XCD's L2, so that the workgroup which needs them finds them
+// at L2 latency -- a workgroup's life is then short, which is what keeps enough
+// bytes in flight per CU; (3) barrier; (4) two decode-and-store steps: thread t
+// handles EPL consecutive elements at (step * 512 + t) * EPL, so each wave store
+// instruction writes one contiguous 1 KiB run (8 whole 128-byte lines) and the
+// workgroup writes two contiguous 8 KiB runs.
 template <class F, class O, bool NT>
-__device__ __forceinline__ void tile_decode(const uint4v *lds, uint32_t off0, uint32_t nblk,
-                                            typename O::T *out, uint32_t lane) {
+__device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32_t nblk,
+                                         typename O::T *out, const uint8_t *pf) {
+    typedef TileGeom<F, O> G;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t off0 = (uint32_t)((uintptr_t)src & 15u);
+    const uint4v *base16 = (const uint4v *)(src - off0);
+    const uint32_t nslots = (off0 + nblk * F::BYTES + 15u) >> 4;
+#pragma unroll
+    for (uint32_t k = 0; k < G::LPT; ++k) {
+        uint32_t s = tid + WG_THREADS * k;
+        if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + s);
+    }
+    uint32_t touch = 0;
+    if (pf != nullptr) {
+        // only lines that hold bytes of that tile: nothing outside the tensor is read
+        const uint8_t *line = (const uint8_t *)((uintptr_t)pf & ~(uintptr_t)127) + 128u * tid;
+        if (line < pf + G::TBYTES) touch = *(const uint32_t *)line;
+    }
+    __syncthreads();
     LdsBytes r{(const uint32_t *)lds};
-    constexpr uint32_t STEPS = TILE_ELEMS / (64 * O::EPL);
-#pragma unroll 4
-    for (uint32_t i = 0; i < STEPS; ++i) {
-        uint32_t el = (i * 64 + lane) * O::EPL;
+#pragma unroll
+    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
+        uint32_t el = (i * WG_THREADS + tid) * O::EPL;
         uint32_t bt = el / F::N, e = el % F::N;
         if (bt < nblk) {
             uint32_t b = off0 + bt * F::BYTES;
@@ -141,149 +145,82 @@ __device__ __forceinline__ void tile_decode(const uint4v *lds, uint32_t off0, ui
             }
         }
     }
+    // keeps the prefetch load alive; it is waited for only here, after the stores
+    asm volatile("" ::"v"(touch));
 }
 
-// ---- one tensor per launch --------------------------------------------------
-// Each wave walks tiles wave_id, wave_id + nwaves, ... of the tensor.
+// ---- one tensor per launch: workgroup b decodes tile b ---------------------------
+// The grid covers every tile (no loop): the hardware dispatches workgroups in
+// order, so at any moment the in-flight stores cover one compact, steadily advancing
+// window of the output -- the access pattern HBM serves best.
 template <class F, class O, bool NT>
-__global__ __launch_bounds__(WG_THREADS) void deq_tiles(const uint8_t *__restrict__ src,
-                                                        typename O::T *__restrict__ dst,
-                                                        uint64_t nblocks) {
-    typedef TileGeom<F> G;
-    __shared__ uint4v lds_all[WAVES_PER_WG][G::LDS_SLOTS];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint4v *lds = lds_all[wv];
-
-    const uint64_t head = (uint64_t)src & 15u;
-    const uint4v *base16 = (const uint4v *)(src - head);
-    const uint64_t ntiles = (nblocks + G::TB - 1) / G::TB;
-    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES_PER_WG;
-    uint64_t t = (uint64_t)blockIdx.x * WAVES_PER_WG + wv;
-    if (t >= ntiles) return;
-
-    uint4v reg[G::LPL];
-    // geometry of tile t
-    uint64_t byte0 = head + t * G::TBYTES;
-    uint64_t rem = nblocks - t * G::TB;
-    uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-    uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
-    tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
-
-    for (;;) {
-        tile_stage<F>(lds, reg, nslots, lane);
-        const uint32_t cur_nblk = nblk;
-        const uint32_t off0 = (uint32_t)(byte0 & 15u);
-        const uint64_t cur_t = t;
-        t += nwaves;
-        const bool more = t < ntiles;
-        if (more) {
-            byte0 = head + t * G::TBYTES;
-            rem = nblocks - t * G::TB;
-            nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-            nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
-            tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        tile_decode<F, O, NT>(lds, off0, cur_nblk, dst + cur_t * TILE_ELEMS, lane);
-        if (!more) break;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
+__global__ __launch_bounds__(WG_THREADS) void deq_one(const uint8_t *__restrict__ src,
+                                                      typename O::T *__restrict__ dst,
+                                                      uint64_t nblocks) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint64_t tp = t + PREFETCH_TILES;
+    // the far tile must lie wholly inside the tensor (the prefetch touches every
+    // 128-byte line that holds bytes of that tile, and nothing else)
+    const uint8_t *pf = (tp + 1) * G::TB <= nblocks ? src + tp * G::TBYTES : nullptr;
+    deq_tile<F, O, NT>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, pf);
 }
 
-// ---- many tensors per launch -------------------------------------------------
-// Tiles of all segments are numbered consecutively; a wave finds the segment of
-// its tile by binary search over tile_begin (wave-uniform, scalar loads).
+// ---- many tensors per launch: workgroup b decodes tile table[b] -------------------
 template <class F, class O, bool NT>
-__global__ __launch_bounds__(WG_THREADS) void deq_tiles_batch(const Segment *__restrict__ seg,
-                                                              uint32_t nseg, uint64_t ntiles) {
-    typedef TileGeom<F> G;
-    __shared__ uint4v lds_all[WAVES_PER_WG][G::LDS_SLOTS];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint4v *lds = lds_all[wv];
-    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES_PER_WG;
-    uint64_t t = (uint64_t)blockIdx.x * WAVES_PER_WG + wv;
-    if (t >= ntiles) return;
-
-    // locate(): fill the geometry of tile `tt`
-    uint32_t si = 0;
-    const uint4v *base16;
-    uint64_t byte0;
-    uint32_t nblk, nslots;
-    typename O::T *out;
-    auto locate = [&](uint64_t tt) {
-        // segments are walked forwards only, so resume the search at si
-        uint32_t lo = si, hi = nseg;   // invariant: tile_begin[lo] <= tt
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (seg[mid].tile_begin <= tt) lo = mid; else hi = mid;
-        }
-        si = lo;
-        const uint8_t *s = seg[lo].src;
-        uint64_t lt = tt - seg[lo].tile_begin;
-        uint64_t head = (uint64_t)s & 15u;
-        base16 = (const uint4v *)(s - head);
-        byte0 = head + lt * G::TBYTES;
-        uint64_t rem = seg[lo].blocks - lt * G::TB;
-        nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-        nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
-        out = (typename O::T *)seg[lo].dst + lt * TILE_ELEMS;
-    };
-
-    uint4v reg[G::LPL];
-    locate(t);
-    tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
-    for (;;) {
-        tile_stage<F>(lds, reg, nslots, lane);
-        const uint32_t cur_nblk = nblk;
-        const uint32_t off0 = (uint32_t)(byte0 & 15u);
-        typename O::T *cur_out = out;
-        t += nwaves;
-        const bool more = t < ntiles;
-        if (more) {
-            locate(t);
-            tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        tile_decode<F, O, NT>(lds, off0, cur_nblk, cur_out, lane);
-        if (!more) break;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+__global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restrict__ table,
+                                                        uint64_t ntiles) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const TileRef me = table[t];
+    const uint64_t tp = t + PREFETCH_TILES;
+    const uint8_t *pf = nullptr;
+    if (tp < ntiles) {
+        const TileRef far = table[tp];
+        // whole tiles only (a short tile is a tensor's last one)
+        if ((far.src_nblk >> 48) == G::TB) pf = (const uint8_t *)(far.src_nblk & 0xFFFFFFFFFFFFull);
     }
+    deq_tile<F, O, NT>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint32_t)(me.src_nblk >> 48),
+                       (typename O::T *)me.dst, pf);
 }
 
 // ---- F16 / BF16 sources: plain widening, no LDS -------------------------------
-// (ggml-quants/src/structs/half.rs:19-21, 35-37).  Lane l of a step converts
-// elements [4l, 4l+4) of a 256-element run from one 8-byte load and writes one
-// 16-byte store (f32 out) so loads and stores are both contiguous per wave.
+// (ggml-quants/src/structs/half.rs:19-21, 35-37).  Same one-shot shape: a thread
+// converts 4 consecutive elements per step from one 8-byte load into one 16-byte
+// store (f32 out; 8 bytes for 2-byte outputs), two steps per thread, so a workgroup
+// reads 8 KiB and writes 16 KiB, both contiguous.
 // Requires src 8-byte aligned and dst 16-byte aligned; n4 = elements / 4.
 template <bool BF16SRC, class O, bool NT>
-__global__ __launch_bounds__(WG_THREADS) void widen_vec(const uint2 *__restrict__ src,
+__global__ __launch_bounds__(WG_THREADS) void widen_vec(const uint2v *__restrict__ src,
                                                         typename O::T *__restrict__ dst, uint64_t n4) {
-    uint64_t i = (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * WG_THREADS;
-    for (; i < n4; i += stride) {
-        uint2 v = src[i];
+    const uint64_t base = (uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x;
+    uint2v v[STORES_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < STORES_PER_THREAD; ++k) {
+        uint64_t i = base + k * WG_THREADS;
+        if (i < n4) v[k] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < STORES_PER_THREAD; ++k) {
+        uint64_t i = base + k * WG_THREADS;
+        if (i >= n4) continue;
         float y[4];
         if (BF16SRC) {
-            y[0] = __uint_as_float(v.x << 16); y[1] = __uint_as_float(v.x & 0xFFFF0000u);
-            y[2] = __uint_as_float(v.y << 16); y[3] = __uint_as_float(v.y & 0xFFFF0000u);
+            y[0] = __uint_as_float(v[k].x << 16); y[1] = __uint_as_float(v[k].x & 0xFFFF0000u);
+            y[2] = __uint_as_float(v[k].y << 16); y[3] = __uint_as_float(v[k].y & 0xFFFF0000u);
         } else {
-            y[0] = h2f(v.x & 0xFFFFu); y[1] = h2f(v.x >> 16);
-            y[2] = h2f(v.y & 0xFFFFu); y[3] = h2f(v.y >> 16);
+            y[0] = h2f(v[k].x & 0xFFFFu); y[1] = h2f(v[k].x >> 16);
+            y[2] = h2f(v[k].y & 0xFFFFu); y[3] = h2f(v[k].y >> 16);
         }
         if constexpr (O::EPL == 4) {
             O::template store<NT>(dst + 4 * i, y);
         } else {
-            // 2-byte outputs: 8 bytes per lane
-            uint2 o = {O::pk(y[0], y[1]), O::pk(y[2], y[3])};
-            *(uint2 *)(dst + 4 * i) = o;
+            uint2v o = {O::pk(y[0], y[1]), O::pk(y[2], y[3])};
+            *(uint2v *)(dst + 4 * i) = o;
         }
     }
 }

@@ -1,0 +1,401 @@
+// kernels_v2.h -- experimental kernel variants measured by ubench against the
+// shipped ones in kernels.h.  A variant that wins moves into kernels.h.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace ggq {
+
+// ---- the first design, kept for A/B: persistent waves walking 4096-element tiles
+// ---- with a grid-stride loop and register prefetch of the next tile.  It loses to
+// ---- the one-shot grid (kernels.h) by 15-20 %: looping workgroups drift apart and
+// ---- their stores stop forming a compact advancing window.
+constexpr uint32_t TILE_ELEMS = 4096;
+constexpr uint32_t WAVES_PER_WG = 4;
+constexpr uint32_t OLD_WG_THREADS = 64 * WAVES_PER_WG;
+
+template <class F, uint32_t TE = TILE_ELEMS>
+struct OldGeom {
+    static constexpr uint32_t ELEMS = TE;
+    static constexpr uint32_t TB = TE / F::N;                 // blocks per tile
+    static constexpr uint32_t TBYTES = TB * F::BYTES;         // packed bytes per tile
+    static constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1; // 16-byte slots a tile can touch
+    static constexpr uint32_t LDS_SLOTS = SLOTS + 1;          // + slack for the funnel read
+    static constexpr uint32_t LPL = (SLOTS + 63) / 64;        // loads per lane
+    static_assert(TE % F::N == 0 && TE % 512 == 0, "a tile is whole blocks and whole wave steps");
+};
+
+// Issue the aligned 16-byte loads of one tile into registers.
+//   base16 : source pointer rounded down to 16 bytes
+//   slot0  : first slot of the tile, nslots : slots that hold tile bytes
+template <class F>
+__device__ __forceinline__ void tile_fetch(uint4v (&reg)[OldGeom<F>::LPL], const uint4v *base16,
+                                           uint64_t slot0, uint32_t nslots, uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 0; k < OldGeom<F>::LPL; ++k) {
+        uint32_t s = lane + 64 * k;
+        if (s < nslots) reg[k] = __builtin_nontemporal_load(base16 + slot0 + s);
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void tile_stage(uint4v *lds, const uint4v (&reg)[OldGeom<F>::LPL],
+                                           uint32_t nslots, uint32_t lane) {
+#pragma unroll
+    for (uint32_t k = 0; k < OldGeom<F>::LPL; ++k) {
+        uint32_t s = lane + 64 * k;
+        if (s < nslots) lds[s] = reg[k];
+    }
+}
+
+// Decode one staged tile and store it.  `nblk` = blocks of the tile that exist
+// (TB except for a tensor's last tile), off0 = byte offset of the tile's first
+// block inside the LDS image (0..15).
+template <class F, class O, bool NT>
+__device__ __forceinline__ void tile_decode(const uint4v *lds, uint32_t off0, uint32_t nblk,
+                                            typename O::T *out, uint32_t lane) {
+    LdsBytes r{(const uint32_t *)lds};
+    constexpr uint32_t STEPS = TILE_ELEMS / (64 * O::EPL);
+#pragma unroll 4
+    for (uint32_t i = 0; i < STEPS; ++i) {
+        uint32_t el = (i * 64 + lane) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            float y0[4];
+            F::dec4(r, b, e, y0);
+            if constexpr (O::EPL == 4) {
+                O::template store<NT>(out + el, y0);
+            } else {
+                float y1[4];
+                F::dec4(r, b, e + 4, y1);
+                O::template store<NT>(out + el, y0, y1);
+            }
+        }
+    }
+}
+
+// ---- one tensor per launch --------------------------------------------------
+// Each wave walks tiles wave_id, wave_id + nwaves, ... of the tensor.
+template <class F, class O, bool NT>
+__global__ __launch_bounds__(OLD_WG_THREADS) void deq_tiles(const uint8_t *__restrict__ src,
+                                                        typename O::T *__restrict__ dst,
+                                                        uint64_t nblocks) {
+    typedef OldGeom<F> G;
+    __shared__ uint4v lds_all[WAVES_PER_WG][G::LDS_SLOTS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4v *lds = lds_all[wv];
+
+    const uint64_t head = (uint64_t)src & 15u;
+    const uint4v *base16 = (const uint4v *)(src - head);
+    const uint64_t ntiles = (nblocks + G::TB - 1) / G::TB;
+    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES_PER_WG;
+    uint64_t t = (uint64_t)blockIdx.x * WAVES_PER_WG + wv;
+    if (t >= ntiles) return;
+
+    uint4v reg[G::LPL];
+    // geometry of tile t
+    uint64_t byte0 = head + t * G::TBYTES;
+    uint64_t rem = nblocks - t * G::TB;
+    uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+    tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
+
+    for (;;) {
+        tile_stage<F>(lds, reg, nslots, lane);
+        const uint32_t cur_nblk = nblk;
+        const uint32_t off0 = (uint32_t)(byte0 & 15u);
+        const uint64_t cur_t = t;
+        t += nwaves;
+        const bool more = t < ntiles;
+        if (more) {
+            byte0 = head + t * G::TBYTES;
+            rem = nblocks - t * G::TB;
+            nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+            nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+            tile_fetch<F>(reg, base16, byte0 >> 4, nslots, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        tile_decode<F, O, NT>(lds, off0, cur_nblk, dst + cur_t * TILE_ELEMS, lane);
+        if (!more) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Q4_K -> f32 without LDS: a wave takes U consecutive blocks per step.  The 16-byte
+// block header (d, dmin, 12 scale bytes) sits at a wave-uniform address, so it is
+// fetched through the scalar cache and the 6-bit scale unpack runs on the scalar
+// unit; each lane then picks its sub-block's (scale, min) and decodes four values
+// from one dword of qs.  Needs src 4-byte aligned (scalar loads).
+template <bool NT, int U>
+__global__ __launch_bounds__(OLD_WG_THREADS) void q4k_direct(const uint8_t *__restrict__ src,
+                                                         float *__restrict__ dst, uint64_t nblocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES_PER_WG;
+    const uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_WG + wv;
+    const uint32_t is = lane >> 3;
+    const bool low = is < 4;
+    const uint32_t sh8 = 8 * (is & 3), nsh = 4 * (is & 1);
+    const uint32_t qoff = 16 + 32 * (lane >> 4) + 4 * (lane & 7);
+
+    for (uint64_t b0 = w * U; b0 < nblocks; b0 += nwaves * U) {
+        uint4v hdr[U];
+        uint32_t q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + u < nblocks) {
+                const uint8_t *p = src + (b0 + u) * 144;
+                hdr[u] = *(const uint4v *)p;
+                q[u] = __builtin_nontemporal_load((const uint32_t *)(p + qoff));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + u < nblocks) {
+                const uint32_t a0 = hdr[u].y, a1 = hdr[u].z, a2 = hdr[u].w;
+                const float d = h2f(hdr[u].x & 0xFFFFu), dmin = h2f(hdr[u].x >> 16);
+                const uint32_t sc_lo = a0 & 0x3F3F3F3Fu, mn_lo = a1 & 0x3F3F3F3Fu;
+                const uint32_t sc_hi = (a2 & 0x0F0F0F0Fu) | ((a0 >> 2) & 0x30303030u);
+                const uint32_t mn_hi = ((a2 >> 4) & 0x0F0F0F0Fu) | ((a1 >> 2) & 0x30303030u);
+                const uint32_t scw = (low ? sc_lo : sc_hi) >> sh8, mnw = (low ? mn_lo : mn_hi) >> sh8;
+                const float d1 = __fmul_rn(d, ub<0>(scw)), m1 = __fmul_rn(dmin, ub<0>(mnw));
+                const uint32_t wq = (q[u] >> nsh) & 0x0F0F0F0Fu;
+                float y[4];
+                y[0] = __fsub_rn(__fmul_rn(d1, ub<0>(wq)), m1);
+                y[1] = __fsub_rn(__fmul_rn(d1, ub<1>(wq)), m1);
+                y[2] = __fsub_rn(__fmul_rn(d1, ub<2>(wq)), m1);
+                y[3] = __fsub_rn(__fmul_rn(d1, ub<3>(wq)), m1);
+                OutF32::store<NT>(dst + (b0 + u) * 256 + 4 * lane, y);
+            }
+        }
+    }
+}
+
+// One tile of TE elements per wave, no loop: the grid covers every tile, so the
+// hardware's in-order workgroup dispatch keeps all in-flight stores inside one
+// compact, steadily advancing window of the output.
+template <class F, class O, bool NT, uint32_t TE>
+__global__ __launch_bounds__(OLD_WG_THREADS) void deq_oneshot(const uint8_t *__restrict__ src,
+                                                          typename O::T *__restrict__ dst,
+                                                          uint64_t nblocks) {
+    typedef OldGeom<F, TE> G;
+    __shared__ uint4v lds_all[WAVES_PER_WG][G::LDS_SLOTS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4v *lds = lds_all[wv];
+    const uint64_t head = (uint64_t)src & 15u;
+    const uint4v *base16 = (const uint4v *)(src - head);
+    const uint64_t ntiles = (nblocks + G::TB - 1) / G::TB;
+    const uint64_t t = (uint64_t)blockIdx.x * WAVES_PER_WG + wv;
+    if (t >= ntiles) return;
+    const uint64_t byte0 = head + t * G::TBYTES;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+#pragma unroll
+    for (uint32_t k = 0; k < G::LPL; ++k) {
+        uint32_t s = lane + 64 * k;
+        if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + (byte0 >> 4) + s);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    LdsBytes r{(const uint32_t *)lds};
+    const uint32_t off0 = (uint32_t)(byte0 & 15u);
+    typename O::T *out = dst + t * TE;
+    constexpr uint32_t STEPS = TE / (64 * O::EPL);
+#pragma unroll 4
+    for (uint32_t i = 0; i < STEPS; ++i) {
+        uint32_t el = (i * 64 + lane) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            float y0[4];
+            F::dec4(r, b, e, y0);
+            if constexpr (O::EPL == 4) {
+                O::template store<NT>(out + el, y0);
+            } else {
+                float y1[4];
+                F::dec4(r, b, e + 4, y1);
+                O::template store<NT>(out + el, y0, y1);
+            }
+        }
+    }
+}
+
+// One tile of TE elements per WORKGROUP, no loop: all 256 threads stage the tile,
+// one barrier, then every step the workgroup writes one contiguous 4 KiB run.
+// MODE: 0 normal, 1 no global loads, 2 no stores, 4 plain (not nt) loads.
+// PF > 0: also touch the packed bytes of the tile PF workgroups ahead (a load whose
+// value is never used), so that workgroup finds them in L2.
+template <class F, class O, bool NT, uint32_t TE, uint32_t THR = 256, int MODE = 0, int MINW = 1, int PF = 0>
+__global__ __launch_bounds__(THR, MINW) void deq_wgtile(const uint8_t *__restrict__ src,
+                                                         typename O::T *__restrict__ dst,
+                                                         uint64_t nblocks) {
+    constexpr uint32_t TB = TE / F::N, TBYTES = TB * F::BYTES;
+    constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1;
+    constexpr uint32_t LPT = (SLOTS + THR - 1) / THR;
+    __shared__ uint4v lds[SLOTS + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t head = (uint64_t)src & 15u;
+    const uint4v *base16 = (const uint4v *)(src - head);
+    const uint64_t t = blockIdx.x;
+    const uint64_t byte0 = head + t * TBYTES;
+    const uint64_t rem = nblocks - t * TB;
+    const uint32_t nblk = rem < TB ? (uint32_t)rem : TB;
+    const uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+#pragma unroll
+    for (uint32_t k = 0; k < LPT; ++k) {
+        uint32_t s = tid + THR * k;
+        if (MODE == 4) {
+            if (s < nslots) lds[s] = base16[(byte0 >> 4) + s];
+        } else if (MODE != 1) {
+            if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + (byte0 >> 4) + s);
+        } else {
+            if (s < nslots) lds[s] = uint4v{0x3c003c00u + s, s * 77u, s * 1234567u, ~s};
+        }
+    }
+    uint32_t pf = 0;
+    if constexpr (PF > 0) {
+        // one dword per 128-byte line of the future tile
+        const uint64_t pb = ((head + (t + PF) * TBYTES) & ~(uint64_t)127) + 128ull * tid;
+        if (128u * tid < TBYTES + 128 && (t + PF + 1) * TB <= nblocks)
+            pf = *(const uint32_t *)((const uint8_t *)base16 + pb);
+    }
+    __syncthreads();
+    LdsBytes r{(const uint32_t *)lds};
+    const uint32_t off0 = (uint32_t)(byte0 & 15u);
+    typename O::T *out = dst + t * TE;
+    constexpr uint32_t STEPS = TE / (THR * O::EPL);
+    static_assert(STEPS >= 1, "tile too small for the workgroup");
+#pragma unroll 4
+    for (uint32_t i = 0; i < STEPS; ++i) {
+        uint32_t el = (i * THR + tid) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            float y0[4];
+            F::dec4(r, b, e, y0);
+            if constexpr (MODE == 2) {
+                asm volatile("" ::"v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]));
+            } else if constexpr (O::EPL == 4) {
+                O::template store<NT>(out + el, y0);
+            } else {
+                float y1[4];
+                F::dec4(r, b, e + 4, y1);
+                O::template store<NT>(out + el, y0, y1);
+            }
+        }
+    }
+    if constexpr (PF > 0) asm volatile("" ::"v"(pf));
+}
+
+// one-shot mix probe: each thread loads one 16-byte value per 8 stored (the
+// read:write ratio of a 4-bit format), S stores per thread
+template <bool NT, int S>
+__global__ __launch_bounds__(256) void k_mix_shot(float4v *dst, const float4v *src, uint64_t n16) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * 256 * S;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)tid};
+    if (tid < 32 * S) v = __builtin_nontemporal_load(src + (base >> 3) + tid);
+    v.x += __shfl(v.y, (tid * 7) & 63);
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + (uint64_t)k * 256 + tid;
+        if (i < n16) {
+            if (NT) __builtin_nontemporal_store(v, dst + i);
+            else dst[i] = v;
+        }
+    }
+}
+
+// one-shot copy probe, S 16-byte loads then S stores per thread
+template <bool NTL, bool NTS, int S>
+__global__ __launch_bounds__(256) void k_copy_shot(float4v *dst, const float4v *src, uint64_t n16) {
+    const uint64_t base = (uint64_t)blockIdx.x * 256 * S + threadIdx.x;
+    float4v v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+        if (base + k * 256 < n16) v[k] = NTL ? __builtin_nontemporal_load(src + base + k * 256) : src[base + k * 256];
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+        if (base + k * 256 < n16) {
+            if (NTS) __builtin_nontemporal_store(v[k], dst + base + k * 256);
+            else dst[base + k * 256] = v[k];
+        }
+}
+
+// mix probe with the loads spread over all threads: every thread loads 2 bytes... as one
+// dword per 2 threads is awkward, each thread loads one dword (4 B) per 2 stores of 16 B
+template <bool NTL, bool NTS, int S>
+__global__ __launch_bounds__(256) void k_mix_shot2(float4v *dst, const uint32_t *src, uint64_t n16) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * 256 * S;
+    uint32_t w[S / 2];
+#pragma unroll
+    for (int k = 0; k < S / 2; ++k)
+        w[k] = NTL ? __builtin_nontemporal_load(src + (base >> 1) + k * 256 + tid) : src[(base >> 1) + k * 256 + tid];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + (uint64_t)k * 256 + tid;
+        float4v v = {(float)(w[k / 2] & 0xFF), (float)((w[k / 2] >> 8) & 0xFF), (float)((w[k / 2] >> 16) & 0xFF), (float)k};
+        if (i < n16) {
+            if (NTS) __builtin_nontemporal_store(v, dst + i);
+            else dst[i] = v;
+        }
+    }
+}
+
+// write-only probes: one-shot grids, S stores per thread
+//   WGI = true : store k of the workgroup covers one contiguous 4 KiB run
+//   WGI = false: each wave owns a contiguous run of S KiB
+template <bool NT, int S, bool WGI>
+__global__ __launch_bounds__(256) void k_fill_shot(float4v *dst, uint64_t n16) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)tid};
+    const uint64_t base = (uint64_t)blockIdx.x * 256 * S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = WGI ? base + (uint64_t)k * 256 + tid : base + (uint64_t)wv * 64 * S + (uint64_t)k * 64 + lane;
+        if (i < n16) {
+            if (NT) __builtin_nontemporal_store(v, dst + i);
+            else dst[i] = v;
+        }
+    }
+}
+
+// generic write-only probe: THR threads, S stores per thread, layout L:
+//   0 wg-interleaved, 1 wave-contiguous, 2 thread-contiguous (each lane S*16 consecutive bytes)
+template <bool NT, int S, int L, int THR>
+__global__ __launch_bounds__(THR) void k_fill_lay(float4v *dst, uint64_t n16) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)tid};
+    const uint64_t base = (uint64_t)blockIdx.x * THR * S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = L == 0 ? base + (uint64_t)k * THR + tid
+                   : L == 1 ? base + (uint64_t)wv * 64 * S + (uint64_t)k * 64 + lane
+                            : base + (uint64_t)tid * S + k;
+        if (i < n16) {
+            if (NT) __builtin_nontemporal_store(v, dst + i);
+            else dst[i] = v;
+        }
+    }
+}
+
+struct UbVariant {
+    std::string name;
+    double bytes;
+    std::function<void(hipStream_t)> run;
+    std::vector<float> ms;
+};
+
+}  // namespace ggq

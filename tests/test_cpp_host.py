@@ -1,0 +1,27 @@
+"""The C++ host mirror (gguf_amd/host/ggml_quants.hpp) run through its test program,
+which restates the reference's slice-API tests (ggml-quants/src/lib.rs:274-369)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "gguf_amd", "host", "test_slice_api")
+
+
+def _run(*args):
+    assert os.path.exists(EXE), "build it: make -C gguf_amd/host"
+    return subprocess.run([EXE, *args], capture_output=True, text=True, timeout=120)
+
+
+def test_error_cases_without_device():
+    r = _run("--no-device")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "slice api ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_full_program_on_gpu():
+    r = _run()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "slice api ok (with device)" in r.stdout

@@ -73,11 +73,11 @@ def test_kat_and_edge_scales(torch_cuda, oracle, ty):
     assert same_bits16(got, e[f"t{ty}_f16"], "f16")
 
 
-# block counts around the tile size (16 K-blocks / 128 legacy blocks per wave tile),
-# one block, and enough tiles that waves loop
+# block counts around the tile sizes (a workgroup tile is 4096 elements for f32
+# output and 8192 for 2-byte outputs), one block, and many tiles
 def counts_for(n):
     tb = 4096 // n
-    return [1, 2, tb - 1, tb, tb + 1, 3 * tb + 5, 40 * tb + 7]
+    return [1, 2, tb - 1, tb, tb + 1, 2 * tb - 1, 2 * tb, 2 * tb + 1, 3 * tb + 5, 40 * tb + 7]
 
 
 @pytest.mark.parametrize("ty", BLOCK_TYPES)
@@ -114,6 +114,19 @@ def test_widen_all_patterns(torch_cuda, oracle, ty, out):
     for n, off in ((65536, 0), (65533, 0), (1001, 2), (7, 0), (65536, 6)):
         p = bits[:n].view(np.uint8)
         check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, out, off), out)
+
+
+@pytest.mark.parametrize("ty", [12, 14, 2, 8])
+@pytest.mark.parametrize("out", ["f32", "f16"])
+def test_beyond_prefetch_distance(torch_cuda, oracle, ty, out):
+    """More than 2048 tiles in one tensor, so workgroups touch the tile 2048 ahead
+    (the L2 prefetch), with a ragged tail and an odd source alignment."""
+    from gguf_amd import synth
+    n = oracle.block_elems(ty)
+    tile = 4096 if out == "f32" else 8192
+    blocks = (2048 + 37) * tile // n + 3
+    p = synth.random_blocks(ty, blocks, 2048 + ty)
+    check(oracle, ty, p, gpu_decode(torch_cuda, ty, p, out, 6), out)
 
 
 def test_slice_errors_on_device(torch_cuda):
@@ -157,7 +170,9 @@ def test_batch_matches_single(torch_cuda, oracle):
     import gguf_amd as g
     from gguf_amd import synth
     t = torch_cuda
-    specs = [(12, 700), (14, 33), (12, 1), (2, 5000), (14, 260), (12, 16), (8, 129), (1, 5001), (23, 40)]
+    # > 2048 tiles of Q4_K in total, with short tiles in between (prefetch must skip those)
+    specs = [(12, 700), (14, 33), (12, 1), (2, 5000), (14, 260), (12, 16), (8, 129), (1, 5001), (23, 40),
+             (12, 16 * 1500 + 5), (12, 16 * 900), (12, 7), (12, 16 * 300 + 1)]
     tensors, packed = [], []
     for i, (ty, blocks) in enumerate(specs):
         p = synth.random_blocks(ty, blocks, 800 + i)
