@@ -202,7 +202,7 @@ def main():
             "algorithmic_GBps": round((pin + pout) / (elapsed / args.steps) / 1e9, 2),
             "kernels": [{"type": GGmlType(ty).name, "elements": sum(x[2].numel() for x in by_type[ty]),
                          "avg_ms": round(kern_ms[k], 4)} for k, ty in enumerate(order)],
-            "roofline": {"bound": "hbm", "kernel": f"deq_tiles_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)",
+            "roofline": {"bound": "hbm", "kernel": f"deq_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(kern_ms[0], 4)},
