@@ -71,10 +71,13 @@ struct OutBF16 {
 // moment and cost DRAM efficiency; two is the optimum.
 constexpr uint32_t WG_THREADS = 512;
 constexpr uint32_t STORES_PER_THREAD = 2;
-// Distance, in workgroups, of the L2 prefetch (see deq_tile).  A multiple of 8:
-// workgroups b and b + 8k run on the same XCD, so the line lands in the L2 that the
-// later workgroup will read.  About one full chip's worth of resident workgroups.
-constexpr uint32_t PREFETCH_TILES = 2048;
+
+// Burst prefetch schedule, in tiles (= workgroups).  period 0 switches it off.
+// See deq_tile for what it does and why.
+struct Prefetch {
+    uint32_t period;   // a burst of reads is issued once every `period` workgroups
+    uint32_t lead;     // ... for the tiles `lead` workgroups ahead of the burst's first workgroup
+};
 
 template <class F, class O>
 struct TileGeom {
@@ -84,7 +87,10 @@ struct TileGeom {
     static constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1;  // 16-byte slots a tile can touch
     static constexpr uint32_t LDS_SLOTS = SLOTS + 1;           // + slack for the funnel read
     static constexpr uint32_t LPT = (SLOTS + WG_THREADS - 1) / WG_THREADS;   // loads per thread
+    static constexpr uint32_t LINES = (TBYTES + 127) / 128 + 1;  // 128-byte lines a tile can touch
+    static constexpr uint32_t TPW = WG_THREADS / LINES;        // tiles one workgroup can prefetch (a line per thread)
     static_assert(ELEMS % F::N == 0, "a tile is a whole number of blocks");
+    static_assert(TPW >= 1, "tile too large to prefetch with one line per thread");
 };
 
 // One tile of a batch: everything a workgroup needs, in one 16-byte record, so
@@ -94,22 +100,52 @@ struct TileRef {
     uint64_t dst;        // address of the tile's first output element (16-byte aligned)
 };
 
+// Which 128-byte line, if any, this thread touches for the burst prefetch.
+// Workgroups are numbered t = 0, 1, ... in dispatch order; the first
+// NB = ceil(period / TPW) workgroups of every `period` are on prefetch duty: together
+// they touch every line of the `period` tiles that start `lead` tiles after the first
+// workgroup of their period, one line per thread (thread -> (tile j, line l)).
+// `tile_src(tt)` returns the address of tile tt's packed bytes, or null if that tile
+// does not exist or is not a whole tile.
+template <class G, class SrcOf>
+__device__ __forceinline__ const uint8_t *prefetch_line(uint64_t t, Prefetch pf, SrcOf tile_src) {
+    if (pf.period == 0) return nullptr;
+    const uint32_t ph = (uint32_t)(t % pf.period);
+    const uint32_t nb = (pf.period + G::TPW - 1) / G::TPW;
+    if (ph >= nb) return nullptr;
+    const uint32_t j = threadIdx.x / G::LINES, l = threadIdx.x % G::LINES;
+    const uint32_t k = ph * G::TPW + j;             // tile within the prefetched period
+    if (j >= G::TPW || k >= pf.period) return nullptr;
+    const uint8_t *base = tile_src(t - ph + pf.lead + k);
+    if (base == nullptr) return nullptr;
+    const uint8_t *line = (const uint8_t *)((uintptr_t)base & ~(uintptr_t)127) + 128u * l;
+    return line < base + G::TBYTES ? line : nullptr;   // only lines holding bytes of that tile
+}
+
 // Decode one tile.
 //   src   first block of the tile (any alignment), nblk blocks present (<= TB)
 //   out   first output element of the tile (16-byte aligned)
-//   pf    packed bytes of the tile PREFETCH_TILES workgroups ahead, or null
+//   line  a 128-byte line of a far-ahead tile to touch, or null (prefetch_line)
 // Steps: (1) aligned 16-byte loads of the packed bytes into LDS, consecutive
-// threads -> consecutive 16-byte slots of the enclosing 16-byte grid; (2) one dword
-// per 128-byte line of the far-ahead tile is loaded and never used: it only pulls
-// those lines into this XCD's L2, so that the workgroup which needs them finds them
-// at L2 latency -- a workgroup's life is then short, which is what keeps enough
-// bytes in flight per CU; (3) barrier; (4) two decode-and-store steps: thread t
-// handles EPL consecutive elements at (step * 512 + t) * EPL, so each wave store
-// instruction writes one contiguous 1 KiB run (8 whole 128-byte lines) and the
-// workgroup writes two contiguous 8 KiB runs.
-template <class F, class O, bool NT>
+// threads -> consecutive 16-byte slots of the enclosing 16-byte grid.  These are
+// PLAIN loads on purpose: a non-temporal load drops the line from the caches behind
+// it, and whenever tiles do not start on 128-byte lines (any source offset, and every
+// format whose tile is not a multiple of 128 bytes: Q2_K, Q3_K, Q6_K, Q8K) the next
+// workgroup needs that same boundary line again and must fetch it from HBM --
+// measured -13 % on Q4_K at a 16-byte source offset, -14 % on Q6_K; (2) burst
+// prefetch: one dword of `line` is loaded and never used.  The packed input is only
+// ~12 % of the traffic, but reads that trickle into HBM between the writes cost far
+// more than their bytes (every few reads force the memory to turn its bus around).
+// Bunching them -- a few workgroups per period pull a whole period's input, over 1 MB,
+// into the memory-side cache at once -- lets every other workgroup find its input
+// on chip: measured +15 % on Q4_K -> f32 against no prefetch, +8 % against a
+// per-workgroup L2 prefetch of the same lead; (3) barrier; (4) two decode-and-store
+// steps: thread t handles EPL consecutive elements at (step * 512 + t) * EPL, so each
+// wave store instruction writes one contiguous 1 KiB run (8 whole 128-byte lines)
+// and the workgroup writes two contiguous 8 KiB runs.
+template <class F, class O, bool NT, bool NTL = false>
 __device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32_t nblk,
-                                         typename O::T *out, const uint8_t *pf) {
+                                         typename O::T *out, const uint8_t *line) {
     typedef TileGeom<F, O> G;
     const uint32_t tid = threadIdx.x;
     const uint32_t off0 = (uint32_t)((uintptr_t)src & 15u);
@@ -118,14 +154,10 @@ __device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32
 #pragma unroll
     for (uint32_t k = 0; k < G::LPT; ++k) {
         uint32_t s = tid + WG_THREADS * k;
-        if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + s);
+        if (s < nslots) lds[s] = NTL ? __builtin_nontemporal_load(base16 + s) : base16[s];
     }
     uint32_t touch = 0;
-    if (pf != nullptr) {
-        // only lines that hold bytes of that tile: nothing outside the tensor is read
-        const uint8_t *line = (const uint8_t *)((uintptr_t)pf & ~(uintptr_t)127) + 128u * tid;
-        if (line < pf + G::TBYTES) touch = *(const uint32_t *)line;
-    }
+    if (line != nullptr) touch = *(const uint32_t *)line;
     __syncthreads();
     LdsBytes r{(const uint32_t *)lds};
 #pragma unroll
@@ -153,39 +185,37 @@ __device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32
 // The grid covers every tile (no loop): the hardware dispatches workgroups in
 // order, so at any moment the in-flight stores cover one compact, steadily advancing
 // window of the output -- the access pattern HBM serves best.
-template <class F, class O, bool NT>
+template <class F, class O, bool NT, bool NTL = false>
 __global__ __launch_bounds__(WG_THREADS) void deq_one(const uint8_t *__restrict__ src,
                                                       typename O::T *__restrict__ dst,
-                                                      uint64_t nblocks) {
+                                                      uint64_t nblocks, Prefetch pf) {
     typedef TileGeom<F, O> G;
     __shared__ uint4v lds[G::LDS_SLOTS];
     const uint64_t t = blockIdx.x;
     const uint64_t rem = nblocks - t * G::TB;
     const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-    const uint64_t tp = t + PREFETCH_TILES;
-    // the far tile must lie wholly inside the tensor (the prefetch touches every
-    // 128-byte line that holds bytes of that tile, and nothing else)
-    const uint8_t *pf = (tp + 1) * G::TB <= nblocks ? src + tp * G::TBYTES : nullptr;
-    deq_tile<F, O, NT>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, pf);
+    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;   // whole tiles inside the tensor
+    });
+    deq_tile<F, O, NT, NTL>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, line);
 }
 
 // ---- many tensors per launch: workgroup b decodes tile table[b] -------------------
 template <class F, class O, bool NT>
 __global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restrict__ table,
-                                                        uint64_t ntiles) {
+                                                        uint64_t ntiles, Prefetch pf) {
     typedef TileGeom<F, O> G;
     __shared__ uint4v lds[G::LDS_SLOTS];
     const uint64_t t = blockIdx.x;
     const TileRef me = table[t];
-    const uint64_t tp = t + PREFETCH_TILES;
-    const uint8_t *pf = nullptr;
-    if (tp < ntiles) {
-        const TileRef far = table[tp];
+    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[tt].src_nblk;
         // whole tiles only (a short tile is a tensor's last one)
-        if ((far.src_nblk >> 48) == G::TB) pf = (const uint8_t *)(far.src_nblk & 0xFFFFFFFFFFFFull);
-    }
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
     deq_tile<F, O, NT>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint32_t)(me.src_nblk >> 48),
-                       (typename O::T *)me.dst, pf);
+                       (typename O::T *)me.dst, line);
 }
 
 // ---- F16 / BF16 sources: plain widening, no LDS -------------------------------

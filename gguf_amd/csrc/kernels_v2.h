@@ -298,6 +298,119 @@ __global__ __launch_bounds__(THR, MINW) void deq_wgtile(const uint8_t *__restric
     if constexpr (PF > 0) asm volatile("" ::"v"(pf));
 }
 
+// Burst prefetch experiment.  Reads trickling into HBM between the writes cost far
+// more than their bytes (read/write turnarounds).  Here the reads are bunched: the first
+// BURST workgroups of every PERIOD touch, together, ALL packed bytes of the tiles
+// of period +K (one dword per 128-byte line, 512 lines per workgroup), which pulls them
+// into the memory-side Infinity Cache; NEAR > 0 adds the per-workgroup L2 prefetch.
+template <class F, class O, bool NT, uint32_t TE, uint32_t THR, uint32_t PERIOD, uint32_t K, int NEAR>
+__global__ __launch_bounds__(THR) void deq_burst(const uint8_t *__restrict__ src,
+                                                 typename O::T *__restrict__ dst, uint64_t nblocks) {
+    constexpr uint32_t TB = TE / F::N, TBYTES = TB * F::BYTES;
+    constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1;
+    constexpr uint32_t LPT = (SLOTS + THR - 1) / THR;
+    constexpr uint64_t PBYTES = (uint64_t)PERIOD * TBYTES;
+    constexpr uint32_t BURST = (uint32_t)((PBYTES + THR * 128 - 1) / (THR * 128));
+    __shared__ uint4v lds[SLOTS + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t head = (uint64_t)src & 15u;
+    const uint4v *base16 = (const uint4v *)(src - head);
+    const uint64_t t = blockIdx.x;
+    const uint64_t byte0 = head + t * TBYTES;
+    const uint64_t rem = nblocks - t * TB;
+    const uint32_t nblk = rem < TB ? (uint32_t)rem : TB;
+    const uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+    const uint64_t total = nblocks * F::BYTES;
+#pragma unroll
+    for (uint32_t k = 0; k < LPT; ++k) {
+        uint32_t s = tid + THR * k;
+        if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + (byte0 >> 4) + s);
+    }
+    uint32_t pf = 0, pf2 = 0;
+    const uint32_t ph = (uint32_t)(t % PERIOD);
+    if (ph < BURST) {
+        const uint64_t off = ((t / PERIOD + K) * PBYTES & ~(uint64_t)127) + ((uint64_t)ph * THR + tid) * 128;
+        if (off < (t / PERIOD + K + 1) * PBYTES && off + 4 <= total) pf = *(const uint32_t *)(src + off);
+    }
+    if constexpr (NEAR > 0) {
+        const uint64_t pb = ((t + NEAR) * TBYTES & ~(uint64_t)127) + 128ull * tid;
+        if (128u * tid < TBYTES && pb + 4 <= total) pf2 = *(const uint32_t *)(src + pb);
+    }
+    __syncthreads();
+    LdsBytes r{(const uint32_t *)lds};
+    const uint32_t off0 = (uint32_t)(byte0 & 15u);
+    typename O::T *out = dst + t * TE;
+    constexpr uint32_t STEPS = TE / (THR * O::EPL);
+#pragma unroll
+    for (uint32_t i = 0; i < STEPS; ++i) {
+        uint32_t el = (i * THR + tid) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            float y0[4];
+            F::dec4(r, b, e, y0);
+            O::template store<NT>(out + el, y0);
+        }
+    }
+    asm volatile("" ::"v"(pf), "v"(pf2));
+}
+
+// Burst prefetch in BYTE space: the packed input is cut into bursts of CH aligned
+// 64 KiB chunks.  When the decode front enters burst g, the first CH workgroups of that
+// burst each touch one chunk of burst g + K.
+template <class F, class O, bool NT, uint32_t TE, uint32_t THR, uint32_t CH, uint32_t K>
+__global__ __launch_bounds__(THR) void deq_burst2(const uint8_t *__restrict__ src,
+                                                  typename O::T *__restrict__ dst, uint64_t nblocks) {
+    constexpr uint32_t TB = TE / F::N, TBYTES = TB * F::BYTES;
+    constexpr uint32_t SLOTS = (TBYTES + 15) / 16 + 1;
+    constexpr uint32_t LPT = (SLOTS + THR - 1) / THR;
+    constexpr uint64_t CHUNK = 65536, B = (uint64_t)CH * CHUNK;
+    static_assert(THR * 128 == CHUNK, "one line per thread");
+    __shared__ uint4v lds[SLOTS + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t head = (uint64_t)src & 15u;
+    const uint4v *base16 = (const uint4v *)(src - head);
+    const uint64_t t = blockIdx.x;
+    const uint64_t byte0 = head + t * TBYTES;
+    const uint64_t rem = nblocks - t * TB;
+    const uint32_t nblk = rem < TB ? (uint32_t)rem : TB;
+    const uint32_t nslots = (uint32_t)(((byte0 & 15u) + (uint64_t)nblk * F::BYTES + 15u) >> 4);
+    const uint64_t total = nblocks * F::BYTES;
+#pragma unroll
+    for (uint32_t k = 0; k < LPT; ++k) {
+        uint32_t s = tid + THR * k;
+        if (s < nslots) lds[s] = __builtin_nontemporal_load(base16 + (byte0 >> 4) + s);
+    }
+    uint32_t pf = 0;
+    {
+        const uint64_t pos = t * TBYTES;                    // packed offset of this tile
+        const uint64_t g = pos / B;                          // burst the front is in
+        const uint64_t t0 = (g * B + TBYTES - 1) / TBYTES;   // first tile that starts inside burst g
+        const uint64_t ph = t - t0;                          // t >= t0 except for the tile straddling in: then ph wraps huge
+        if (ph < CH) {
+            const uint64_t off = (g + K) * B + ph * CHUNK + (uint64_t)tid * 128;
+            if (off + 4 <= total) pf = *(const uint32_t *)(src + off);
+        }
+    }
+    __syncthreads();
+    LdsBytes r{(const uint32_t *)lds};
+    const uint32_t off0 = (uint32_t)(byte0 & 15u);
+    typename O::T *out = dst + t * TE;
+    constexpr uint32_t STEPS = TE / (THR * O::EPL);
+#pragma unroll
+    for (uint32_t i = 0; i < STEPS; ++i) {
+        uint32_t el = (i * THR + tid) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            float y0[4];
+            F::dec4(r, b, e, y0);
+            O::template store<NT>(out + el, y0);
+        }
+    }
+    asm volatile("" ::"v"(pf));
+}
+
 // one-shot mix probe: each thread loads one 16-byte value per 8 stored (the
 // read:write ratio of a 4-bit format), S stores per thread
 template <bool NT, int S>
@@ -388,6 +501,31 @@ __global__ __launch_bounds__(THR) void k_fill_lay(float4v *dst, uint64_t n16) {
             if (NT) __builtin_nontemporal_store(v, dst + i);
             else dst[i] = v;
         }
+    }
+}
+
+// store-flavour probe: one-shot fill, 512 threads, S stores per thread, wg-interleaved.
+// FL: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt, 5 sc0, 6 sc0 nt, 7 sc1 nt
+template <int FL>
+__device__ __forceinline__ void store_flavour(float4v *p, float4v v) {
+    if constexpr (FL == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+    if constexpr (FL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int FL, int S, int THR>
+__global__ __launch_bounds__(THR) void k_fill_fl(float4v *dst, uint64_t n16) {
+    const uint32_t tid = threadIdx.x;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)tid};
+    const uint64_t base = (uint64_t)blockIdx.x * THR * S;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + (uint64_t)k * THR + tid;
+        if (i < n16) store_flavour<FL>(dst + i, v);
     }
 }
 

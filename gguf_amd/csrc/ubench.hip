@@ -65,6 +65,57 @@ __global__ __launch_bounds__(256) void k_fill_span(float4v *dst, uint64_t n16) {
 
 typedef UbVariant Variant;   // name, algorithmic bytes per launch, launcher, samples
 
+// period x lead sweep of the shipped kernel for one format / output type
+template <class F, class O>
+void add_sweep(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in, void *d_out, uint64_t elems) {
+    typedef TileGeom<F, O> G;
+    const uint64_t blocks = elems / F::N;
+    const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
+    const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
+    static const uint32_t periods[] = {0, 256, 320, 384, 448, 512, 640, 768, 1024};
+    static const uint32_t leads[] = {768, 1024, 1280, 1536, 2048, 3072};
+    for (uint32_t P : periods)
+        for (uint32_t L : leads) {
+            if (P == 0 && L != leads[0]) continue;
+            if (P && L < P) continue;
+            char label[96];
+            std::snprintf(label, sizeof label, "sw %s P%u L%u", name, P, P ? L : 0);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in,
+                                                 (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}});
+        }
+}
+
+// the same sweep through the batch kernel (per-tile table), one contiguous tensor
+template <class F, class O>
+void add_sweep_batch(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in, void *d_out, uint64_t elems) {
+    typedef TileGeom<F, O> G;
+    const uint64_t blocks = elems / F::N;
+    const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;
+    std::vector<TileRef> tab(ntiles);
+    for (uint64_t t = 0; t < ntiles; ++t) {
+        uint64_t nblk = std::min<uint64_t>(G::TB, blocks - t * G::TB);
+        tab[t] = {((uint64_t)(uintptr_t)d_in + t * G::TBYTES) | (nblk << 48),
+                  (uint64_t)(uintptr_t)d_out + t * G::ELEMS * sizeof(typename O::T)};
+    }
+    TileRef *d_tab;
+    CK(hipMalloc(&d_tab, ntiles * sizeof(TileRef)));
+    CK(hipMemcpy(d_tab, tab.data(), ntiles * sizeof(TileRef), hipMemcpyHostToDevice));
+    const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
+    static const uint32_t periods[] = {0, 1, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 3072, 4096};
+    static const uint32_t leads[] = {512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 6144};
+    for (uint32_t P : periods)
+        for (uint32_t L : leads) {
+            if (P == 0 && L != leads[0]) continue;
+            if (P > 1 && L < P) continue;
+            char label[96];
+            std::snprintf(label, sizeof label, "swb %s P%u L%u", name, P, P ? L : 0);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch<F, O, true>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s,
+                                                 d_tab, ntiles, Prefetch{P, L}); }, {}});
+        }
+}
+
 int main(int argc, char **argv) {
     uint64_t melems = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1024;
     int rounds = argc > 2 ? std::atoi(argv[2]) : 15;
@@ -76,15 +127,15 @@ int main(int argc, char **argv) {
     float *d_out;
     uint8_t *d_in;
     CK(hipMalloc(&d_out, elems * 4));
-    CK(hipMalloc(&d_in, elems * 4 + 4096));        // large enough to be the copy source too
+    CK(hipMalloc(&d_in, elems * 2 + 4096));        // large enough to be the (half-size) copy source too
     // pseudo-random payload with benign f16 headers is not needed for timing, but the
     // bytes should not be constant: fill with a cheap pattern
     {
         std::vector<uint32_t> h(1 << 22);
         uint64_t s = 0x9E3779B97F4A7C15ull;
         for (auto &w : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w = (uint32_t)(s >> 16) & 0x3BFF3BFFu; }
-        for (uint64_t off = 0; off < elems * 4; off += h.size() * 4)
-            CK(hipMemcpy(d_in + off, h.data(), std::min<uint64_t>(h.size() * 4, elems * 4 - off), hipMemcpyHostToDevice));
+        for (uint64_t off = 0; off < elems * 2; off += h.size() * 4)
+            CK(hipMemcpy(d_in + off, h.data(), std::min<uint64_t>(h.size() * 4, elems * 2 - off), hipMemcpyHostToDevice));
     }
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -158,6 +209,24 @@ int main(int argc, char **argv) {
     vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                            \
                       hipLaunchKernelGGL((k_fill_lay<NTF, S, L, THR>), dim3((unsigned)(n16 / (THR * S))), dim3(THR), 0, s, \
                                          (float4v *)d_out, n16); }, {}});
+#define FFL(FL, S, THR, LABEL)                                                                              \
+    vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                            \
+                      hipLaunchKernelGGL((k_fill_fl<FL, S, THR>), dim3((unsigned)(n16 / (THR * S))), dim3(THR), 0, s, \
+                                         (float4v *)d_out, n16); }, {}});
+    FFL(0, 2, 512, "fl S2 thr512 plain")
+    FFL(1, 2, 512, "fl S2 thr512 nt")
+    FFL(2, 2, 512, "fl S2 thr512 sc1")
+    FFL(3, 2, 512, "fl S2 thr512 sc0 sc1")
+    FFL(4, 2, 512, "fl S2 thr512 sc0 sc1 nt")
+    FFL(5, 2, 512, "fl S2 thr512 sc0")
+    FFL(6, 2, 512, "fl S2 thr512 sc0 nt")
+    FFL(7, 2, 512, "fl S2 thr512 sc1 nt")
+    FFL(0, 1, 256, "fl S1 thr256 plain")
+    FFL(1, 1, 256, "fl S1 thr256 nt")
+    FFL(3, 1, 256, "fl S1 thr256 sc0 sc1")
+    FFL(0, 4, 256, "fl S4 thr256 plain")
+    FFL(3, 4, 256, "fl S4 thr256 sc0 sc1")
+    FFL(7, 4, 256, "fl S4 thr256 sc1 nt")
     FLAY(true, 1, 0, 256, "lay S1 thr256 nt")
     FLAY(true, 1, 0, 64, "lay S1 thr64 nt")
     FLAY(true, 1, 0, 1024, "lay S1 thr1024 nt")
@@ -241,8 +310,144 @@ int main(int argc, char **argv) {
         double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));                   \
         vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
                           hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,     \
-                                             (const uint8_t *)d_in, (typename O::T *)d_out, blocks); }, {}}); \
+                                             (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{512, 1536}); }, {}}); \
     }
+#define BURST(PERIOD, K, NEAR, LABEL)                                                                       \
+    {                                                                                                       \
+        uint64_t blocks = elems / 256;                                                                      \
+        unsigned grid = (unsigned)((blocks + 15) / 16);                                                     \
+        vs.push_back({LABEL, (double)elems * 4.5625, [=](hipStream_t s) {                                   \
+                          hipLaunchKernelGGL((deq_burst<Q4K, OutF32, true, 4096, 512, PERIOD, K, NEAR>), dim3(grid), dim3(512), 0, s, \
+                                             (const uint8_t *)d_in, d_out, blocks); }, {}});                \
+    }
+#define BURSTG(F, TE, THR, PERIOD, K, LABEL)                                                                \
+    {                                                                                                       \
+        uint64_t blocks = elems / F::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + TE / F::N - 1) / (TE / F::N));                                 \
+        double bytes = (double)elems * ((double)F::BYTES / F::N + 4);                                       \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((deq_burst<F, OutF32, true, TE, THR, PERIOD, K, 0>), dim3(grid), dim3(THR), 0, s, \
+                                             (const uint8_t *)d_in, d_out, blocks); }, {}});                \
+    }
+#define BURST2(F, CH, K, LABEL)                                                                             \
+    {                                                                                                       \
+        uint64_t blocks = elems / F::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + 4096 / F::N - 1) / (4096 / F::N));                             \
+        double bytes = (double)elems * ((double)F::BYTES / F::N + 4);                                       \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((deq_burst2<F, OutF32, true, 4096, 512, CH, K>), dim3(grid), dim3(512), 0, s, \
+                                             (const uint8_t *)d_in, d_out, blocks); }, {}});                \
+    }
+    BURST2(Q4K, 18, 3, "b5 Q4K CH18 K3")
+    BURST2(Q4K, 9, 6, "b5 Q4K CH9 K6")
+    BURST2(Q4K, 36, 2, "b5 Q4K CH36 K2")
+    BURST2(Q4K, 16, 3, "b5 Q4K CH16 K3")
+    BURST2(Q4K, 20, 3, "b5 Q4K CH20 K3")
+    BURST2(Q6K, 18, 3, "b5 Q6K CH18 K3")
+    BURST2(Q6K, 18, 4, "b5 Q6K CH18 K4")
+    BURST2(Q6K, 26, 3, "b5 Q6K CH26 K3")
+    BURST2(Q6K, 26, 2, "b5 Q6K CH26 K2")
+    BURST2(Q6K, 13, 6, "b5 Q6K CH13 K6")
+    BURST2(Q2K, 18, 3, "b5 Q2K CH18 K3")
+    BURST2(Q2K, 10, 3, "b5 Q2K CH10 K3")
+    BURST2(Q2K, 11, 3, "b5 Q2K CH11 K3")
+    BURST2(Q8_0, 18, 3, "b5 Q8_0 CH18 K3")
+    BURST2(Q8_0, 34, 3, "b5 Q8_0 CH34 K3")
+    SHIP(Q6K, OutF32, "b5 ref: ship Q6K f32")
+    SHIP(Q2K, OutF32, "b5 ref: ship Q2K f32")
+    SHIP(Q8_0, OutF32, "b5 ref: ship Q8_0 f32")
+    BURSTG(Q4K, 4096, 512, 512, 3, "b4 Q4K 512x4096 P512 K3")
+    BURSTG(Q4K, 2048, 256, 1024, 3, "b4 Q4K 256x2048 P1024 K3")
+    BURSTG(Q4K, 2048, 256, 1024, 2, "b4 Q4K 256x2048 P1024 K2")
+    BURSTG(Q4K, 4096, 256, 512, 3, "b4 Q4K 256x4096 P512 K3")
+    BURSTG(Q4K, 8192, 512, 256, 3, "b4 Q4K 512x8192 P256 K3")
+    BURSTG(Q4K, 8192, 1024, 256, 3, "b4 Q4K 1024x8192 P256 K3")
+    BURSTG(Q6K, 4096, 512, 512, 3, "b4 Q6K 512x4096 P512 K3")
+    BURSTG(Q6K, 4096, 512, 512, 2, "b4 Q6K 512x4096 P512 K2")
+    BURSTG(Q6K, 4096, 512, 512, 4, "b4 Q6K 512x4096 P512 K4")
+    BURSTG(Q6K, 4096, 512, 384, 4, "b4 Q6K 512x4096 P384 K4")
+    BURSTG(Q6K, 4096, 512, 256, 6, "b4 Q6K 512x4096 P256 K6")
+    BURSTG(Q6K, 4096, 512, 1024, 2, "b4 Q6K 512x4096 P1024 K2")
+    BURSTG(Q4_0, 4096, 512, 512, 3, "b4 Q4_0 512x4096 P512 K3")
+    BURSTG(Q8_0, 4096, 512, 512, 3, "b4 Q8_0 512x4096 P512 K3")
+    BURSTG(Q2K, 4096, 512, 512, 3, "b4 Q2K 512x4096 P512 K3")
+    SHIP(Q6K, OutF32, "b4 ref: ship Q6K f32")
+    SHIP(Q4K, OutF32, "b4 ref: ship Q4K f32")
+    BURST(512, 3, 0, "b3 P512 K3")
+    BURST(512, 4, 0, "b3 P512 K4")
+    BURST(512, 5, 0, "b3 P512 K5")
+    BURST(512, 6, 0, "b3 P512 K6")
+    BURST(512, 8, 0, "b3 P512 K8")
+    BURST(384, 4, 0, "b3 P384 K4")
+    BURST(384, 5, 0, "b3 P384 K5")
+    BURST(768, 2, 0, "b3 P768 K2")
+    BURST(768, 3, 0, "b3 P768 K3")
+    BURST(640, 3, 0, "b3 P640 K3")
+    BURST(448, 4, 0, "b3 P448 K4")
+    BURST(1024, 2, 0, "b3 P1024 K2")
+    SHIP(Q4K, OutF32, "b3 ref: ship Q4K f32")
+    BURST(1024, 1, 0, "b2 P1024 K1")
+    BURST(512, 1, 0, "b2 P512 K1")
+    BURST(512, 2, 0, "b2 P512 K2")
+    BURST(512, 3, 0, "b2 P512 K3")
+    BURST(256, 2, 0, "b2 P256 K2")
+    BURST(256, 4, 0, "b2 P256 K4")
+    BURST(128, 8, 0, "b2 P128 K8")
+    BURST(1536, 1, 0, "b2 P1536 K1")
+    BURST(1024, 1, 512, "b2 P1024 K1 near512")
+    BURST(1024, 1, 256, "b2 P1024 K1 near256")
+    BURST(512, 2, 256, "b2 P512 K2 near256")
+    SHIP(Q4K, OutF32, "b2 ref: ship Q4K f32")
+    BURST(1024, 1, 0, "burst P1024 K1")
+    BURST(1024, 2, 0, "burst P1024 K2")
+    BURST(2048, 1, 0, "burst P2048 K1")
+    BURST(2048, 2, 0, "burst P2048 K2")
+    BURST(4096, 1, 0, "burst P4096 K1")
+    BURST(8192, 1, 0, "burst P8192 K1")
+    BURST(16384, 1, 0, "burst P16384 K1")
+    BURST(2048, 2, 1024, "burst P2048 K2 near1024")
+    BURST(4096, 2, 1024, "burst P4096 K2 near1024")
+    BURST(8192, 1, 1024, "burst P8192 K1 near1024")
+    BURST(256, 8, 0, "burst P256 K8")
+    SHIP(Q4K, OutF32, "burst ref: ship Q4K f32")
+#define SHIPO(F, O, OFF, P, L, LABEL)                                                                       \
+    {                                                                                                       \
+        typedef TileGeom<F, O> G;                                                                           \
+        uint64_t blocks = elems / F::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
+        double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));                   \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,     \
+                                             (const uint8_t *)d_in + OFF, (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}}); \
+    }
+#define SHIPL(F, O, OFF, P, L, LABEL)                                                                       \
+    {                                                                                                       \
+        typedef TileGeom<F, O> G;                                                                           \
+        uint64_t blocks = elems / F::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
+        double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));                   \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((deq_one<F, O, true, false>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                             (const uint8_t *)d_in + OFF, (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}}); \
+    }
+    SHIPL(Q4K, OutF32, 0, 768, 1280, "mis plainld Q4K off0 P768 L1280")
+    SHIPL(Q4K, OutF32, 16, 768, 1280, "mis plainld Q4K off16 P768 L1280")
+    SHIPL(Q4K, OutF32, 2, 768, 1280, "mis plainld Q4K off2 P768 L1280")
+    SHIPL(Q6K, OutF32, 0, 512, 768, "mis plainld Q6K off0 P512 L768")
+    SHIPL(Q6K, OutF32, 0, 768, 1280, "mis plainld Q6K off0 P768 L1280")
+    SHIPL(Q2K, OutF32, 0, 1280, 1280, "mis plainld Q2K off0 P1280 L1280")
+    SHIPL(Q3K, OutF32, 0, 1024, 1280, "mis plainld Q3K off0 P1024 L1280")
+    SHIPO(Q3K, OutF32, 0, 1024, 1280, "mis Q3K off0 P1024 L1280")
+    SHIPO(Q6K, OutF32, 0, 768, 1280, "mis Q6K off0 P768 L1280")
+    SHIPO(Q4K, OutF32, 0, 768, 1280, "mis Q4K off0 P768 L1280")
+    SHIPO(Q4K, OutF32, 16, 768, 1280, "mis Q4K off16 P768 L1280")
+    SHIPO(Q4K, OutF32, 64, 768, 1280, "mis Q4K off64 P768 L1280")
+    SHIPO(Q4K, OutF32, 2, 768, 1280, "mis Q4K off2 P768 L1280")
+    SHIPO(Q4K, OutF32, 0, 0, 0, "mis Q4K off0 nopf")
+    SHIPO(Q4K, OutF32, 16, 0, 0, "mis Q4K off16 nopf")
+    SHIPO(Q4K, OutF32, 2, 0, 0, "mis Q4K off2 nopf")
+    SHIPO(Q6K, OutF32, 0, 512, 768, "mis Q6K off0 P512 L768")
+    SHIPO(Q2K, OutF32, 0, 1280, 1280, "mis Q2K off0 P1280 L1280")
     SHIP(Q4K, OutF32, "ship Q4K f32")
     SHIP(Q6K, OutF32, "ship Q6K f32")
     SHIP(Q2K, OutF32, "ship Q2K f32")
@@ -344,6 +549,38 @@ int main(int argc, char **argv) {
     FSHOT(false, 1, true, "cal fill shot plain S1")
     FSHOT(true, 2, true, "probe fill shot nt S2")
     FSHOT(false, 2, true, "probe fill shot plain S2")
+    if (argc > 3 && std::strncmp(argv[3], "sw", 2) == 0) {
+        vs.clear();
+        add_sweep<Q4K, OutF32>(vs, "Q4K f32", d_in, d_out, elems);
+        add_sweep<Q6K, OutF32>(vs, "Q6K f32", d_in, d_out, elems);
+        add_sweep<Q2K, OutF32>(vs, "Q2K f32", d_in, d_out, elems);
+        add_sweep<Q3K, OutF32>(vs, "Q3K f32", d_in, d_out, elems);
+        add_sweep<Q5K, OutF32>(vs, "Q5K f32", d_in, d_out, elems);
+        add_sweep<Q8K, OutF32>(vs, "Q8K f32", d_in, d_out, elems);
+        add_sweep<IQ4XS, OutF32>(vs, "IQ4XS f32", d_in, d_out, elems);
+        add_sweep<Q4_0, OutF32>(vs, "Q4_0 f32", d_in, d_out, elems);
+        add_sweep<Q4_1, OutF32>(vs, "Q4_1 f32", d_in, d_out, elems);
+        add_sweep<Q5_0, OutF32>(vs, "Q5_0 f32", d_in, d_out, elems);
+        add_sweep<Q5_1, OutF32>(vs, "Q5_1 f32", d_in, d_out, elems);
+        add_sweep<Q8_0, OutF32>(vs, "Q8_0 f32", d_in, d_out, elems);
+        add_sweep<Q8_1, OutF32>(vs, "Q8_1 f32", d_in, d_out, elems);
+        add_sweep<Q4K, OutF16>(vs, "Q4K f16", d_in, d_out, elems);
+        add_sweep<Q6K, OutF16>(vs, "Q6K f16", d_in, d_out, elems);
+        add_sweep<Q8_0, OutF16>(vs, "Q8_0 f16", d_in, d_out, elems);
+        add_sweep<Q4_0, OutF16>(vs, "Q4_0 f16", d_in, d_out, elems);
+        add_sweep<Q2K, OutF16>(vs, "Q2K f16", d_in, d_out, elems);
+    }
+    if (argc > 4 && std::strncmp(argv[3], "swb", 3) == 0) {
+        vs.clear();
+        std::string f = argv[4];
+#define SWB(F, O, NAME) if (f == NAME) add_sweep_batch<F, O>(vs, NAME, d_in, d_out, elems);
+        SWB(Q4K, OutF32, "Q4K_f32") SWB(Q6K, OutF32, "Q6K_f32") SWB(Q2K, OutF32, "Q2K_f32") SWB(Q3K, OutF32, "Q3K_f32")
+        SWB(Q5K, OutF32, "Q5K_f32") SWB(Q8K, OutF32, "Q8K_f32") SWB(IQ4XS, OutF32, "IQ4XS_f32") SWB(IQ4NL, OutF32, "IQ4NL_f32")
+        SWB(Q4_0, OutF32, "Q4_0_f32") SWB(Q4_1, OutF32, "Q4_1_f32") SWB(Q5_0, OutF32, "Q5_0_f32") SWB(Q5_1, OutF32, "Q5_1_f32")
+        SWB(Q8_0, OutF32, "Q8_0_f32") SWB(Q8_1, OutF32, "Q8_1_f32")
+        SWB(Q4K, OutF16, "Q4K_f16") SWB(Q6K, OutF16, "Q6K_f16") SWB(Q8_0, OutF16, "Q8_0_f16") SWB(Q4_0, OutF16, "Q4_0_f16")
+        SWB(Q2K, OutF16, "Q2K_f16") SWB(Q5K, OutF16, "Q5K_f16") SWB(Q3K, OutF16, "Q3K_f16")
+    }
     if (argc > 3) {
         std::vector<Variant> keep;
         for (auto &v : vs) if (v.name.find(argv[3]) != std::string::npos) keep.push_back(v);
