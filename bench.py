@@ -108,11 +108,20 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    # Normal case: one rank per GPU over RCCL.  Rehearsal case (fewer GPUs than ranks,
+    # e.g. two ranks on a one-GPU box): ranks share devices and the process group is gloo
+    # on host tensors -- the group only carries the barriers and the max of the times.
+    shared = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- the job: `world` tensor sets, dealt to ranks by the index partition -------
     base = synth.workload(args.workload)
@@ -161,7 +170,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -193,7 +202,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8->" + args.out, "data": "synthetic",
-            "config": {"workload": args.workload if world == 1 else f"{world} x {args.workload}",
+            "config": {"workload": (args.workload if world == 1 else f"{world} x {args.workload}")
+                       + (f" (REHEARSAL: {world} ranks share {ndev} GPU)" if shared else ""),
                        "tensors": len(items), "elements": total_elems, "packed_bytes": pin,
                        "decoded_bytes": pout, "partition": "index (LPT), no collective",
                        "kernel_launches_per_step": launches},
