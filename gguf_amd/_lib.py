@@ -39,6 +39,8 @@ SYMBOLS = {
     "ggq_device_count": (_int, []),
     "ggq_dequantize_slice": (_int, [_u32, _u32, _vp, _sz, _vp, _sz]),
     "ggq_dequantize_device": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
+    "ggq_quantize_slice": (_int, [_u32, _u32, _vp, _sz, _vp, _sz]),
+    "ggq_quantize_device": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
     "ggq_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
     "ggq_batch_run": (_int, [_vp, _vp]),
     "ggq_batch_launches": (_sz, [_vp]),

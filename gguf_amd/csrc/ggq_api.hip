@@ -4,6 +4,7 @@
 // each entry point replaces.
 #include "../../include/ggq.h"
 #include "kernels.h"
+#include "quantize.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -205,6 +206,82 @@ ggq_status launch_out(uint32_t ty, uint32_t out_ty, void *d_dst, const void *d_s
     case GGQ_TYPE_F32: return launch_any<OutF32>(ty, d_dst, d_src, blocks, cus, st);
     case GGQ_TYPE_F16: return launch_any<OutF16>(ty, d_dst, d_src, blocks, cus, st);
     case GGQ_TYPE_BF16: return launch_any<OutBF16>(ty, d_dst, d_src, blocks, cus, st);
+    default: return GGQ_UNSUPPORTED;
+    }
+}
+
+// ---- quantize -----------------------------------------------------------------------
+bool can_quantize(uint32_t ty) {
+    switch (ty) {
+    case GGQ_TYPE_F16: case GGQ_TYPE_BF16: case GGQ_TYPE_Q4_0: case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0:
+    case GGQ_TYPE_Q5_1: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: case GGQ_TYPE_Q8K: return true;
+    default: return false;
+    }
+}
+
+// Checks of ggml-quants/src/lib.rs:122-127, in that order.
+ggq_status check_quantize(uint32_t ty, uint32_t in_ty, size_t dst_blocks, size_t src_elems) {
+    const TypeInfo *ti = type_info(ty);
+    if (!ti || !can_quantize(ty) || out_bytes(in_ty) == 0) return GGQ_UNSUPPORTED;
+    if (src_elems % ti->elems != 0) return GGQ_INDIVISIBLE;
+    if (dst_blocks != src_elems / ti->elems) return GGQ_LENGTH_MISMATCH;
+    return GGQ_OK;
+}
+
+template <class In, class O>
+ggq_status launch_narrow(void *d_dst, const void *d_src, uint64_t n, int cus, hipStream_t st) {
+    typedef typename In::T TI;
+    typedef typename O::T TO;
+    const uint64_t nvec = n / In::EPL * In::EPL;
+    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD * In::EPL;
+    for (uint64_t i0 = 0; i0 < nvec; i0 += kMaxGrid * per_wg) {
+        uint64_t cnt = std::min(kMaxGrid * per_wg, nvec - i0);
+        hipLaunchKernelGGL((narrow_vec<In, O>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)), dim3(WG_THREADS),
+                           0, st, (const TI *)d_src + i0, (TO *)d_dst + i0, cnt);
+    }
+    if (nvec < n) {
+        hipLaunchKernelGGL((narrow_scalar<In, O>), dim3(1), dim3(WG_THREADS), 0, st, (const TI *)d_src,
+                           (TO *)d_dst, nvec, n);
+    }
+    (void)cus;
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
+template <class In>
+ggq_status launch_quant(uint32_t ty, void *d_dst, const void *d_src, uint64_t blocks, int cus, hipStream_t st) {
+    if (blocks == 0) return GGQ_OK;
+    if (ty == GGQ_TYPE_F16) return launch_narrow<In, OutF16>(d_dst, d_src, blocks, cus, st);
+    if (ty == GGQ_TYPE_BF16) return launch_narrow<In, OutBF16>(d_dst, d_src, blocks, cus, st);
+    switch (ty) {
+#define XQ(ID, Q)                                                                                  \
+    case ID: {                                                                                     \
+        typedef QuantGeom<Q, In> G;                                                                \
+        const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;                                      \
+        for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                       \
+            uint64_t n = std::min(kMaxGrid, ntiles - t0);                                          \
+            hipLaunchKernelGGL((quant_one<Q, In>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st,     \
+                               (const typename In::T *)d_src + t0 * G::ELEMS,                      \
+                               (uint8_t *)d_dst + t0 * G::TBYTES, blocks - t0 * G::TB);            \
+        }                                                                                          \
+        break;                                                                                     \
+    }
+        XQ(GGQ_TYPE_Q4_0, EncQ4_0) XQ(GGQ_TYPE_Q4_1, EncQ4_1) XQ(GGQ_TYPE_Q5_0, EncQ5_0) XQ(GGQ_TYPE_Q5_1, EncQ5_1)
+        XQ(GGQ_TYPE_Q8_0, EncQ8_0) XQ(GGQ_TYPE_Q8_1, EncQ8_1) XQ(GGQ_TYPE_Q8K, EncQ8K)
+#undef XQ
+    default:
+        return GGQ_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
+ggq_status launch_quant_in(uint32_t ty, uint32_t in_ty, void *d_dst, const void *d_src, uint64_t blocks, int cus,
+                           hipStream_t st) {
+    switch (in_ty) {
+    case GGQ_TYPE_F32: return launch_quant<InF32>(ty, d_dst, d_src, blocks, cus, st);
+    case GGQ_TYPE_F16: return launch_quant<InF16>(ty, d_dst, d_src, blocks, cus, st);
+    case GGQ_TYPE_BF16: return launch_quant<InBF16>(ty, d_dst, d_src, blocks, cus, st);
     default: return GGQ_UNSUPPORTED;
     }
 }
@@ -477,6 +554,80 @@ ggq_status ggq_dequantize_slice(uint32_t ty, uint32_t out_ty, void *dst, size_t 
     }
     for (int k = 0; k < ggq_ctx::SLOTS; ++k) {
         int kk = (slot + k) % ggq_ctx::SLOTS;   // oldest first
+        if (rc == GGQ_OK) { if (!drain(kk)) rc = GGQ_DEVICE; }
+        else { (void)hipStreamSynchronize(c->stream[kk]); c->busy[kk] = false; }
+    }
+    pool_put(c);
+    return rc;
+}
+
+// ---- quantize -----------------------------------------------------------------------
+ggq_status ggq_quantize_device(uint32_t ty, uint32_t in_ty, void *d_dst, size_t dst_blocks, const void *d_src,
+                               size_t src_elems, void *hip_stream) {
+    ggq_status st = check_quantize(ty, in_ty, dst_blocks, src_elems);
+    if (st != GGQ_OK) return st;
+    if (dst_blocks == 0) return GGQ_OK;
+    if (!d_dst || !d_src) return GGQ_INVALID;
+    if ((uintptr_t)d_dst % 16 != 0 || (uintptr_t)d_src % 16 != 0) return GGQ_MISALIGNED;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DevInfo di;
+    st = dev_info(dev, di);
+    if (st != GGQ_OK) return st;
+    return launch_quant_in(ty, in_ty, d_dst, d_src, dst_blocks, di.cus, (hipStream_t)hip_stream);
+}
+
+ggq_status ggq_quantize_slice(uint32_t ty, uint32_t in_ty, void *dst, size_t dst_blocks, const void *src,
+                              size_t src_elems) {
+    ggq_status st = check_quantize(ty, in_ty, dst_blocks, src_elems);
+    if (st != GGQ_OK) return st;
+    if (dst_blocks == 0) return GGQ_OK;
+    if (!dst || !src) return GGQ_INVALID;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    ggq_ctx *c = nullptr;
+    st = pool_get(dev, &c);
+    if (st != GGQ_OK) return st;
+    // The pool's pipelines are sized for decoding (small packed side, large element side);
+    // quantizing runs them backwards: elements travel through the large buffers
+    // (h_out / d_out), packed blocks come back through the small ones (h_in / d_in).
+    const TypeInfo *ti = type_info(ty);
+    const size_t ib = out_bytes(in_ty);
+    const size_t chunk_blocks = kHostChunkElems / ti->elems;
+    const uint8_t *s = (const uint8_t *)src;
+    uint8_t *d = (uint8_t *)dst;
+    struct Pending { size_t out_off, out_len; } pend[ggq_ctx::SLOTS] = {};
+    ggq_status rc = GGQ_OK;
+    size_t done_blocks = 0;
+    int slot = 0;
+    auto drain = [&](int k) -> bool {
+        if (!c->busy[k]) return true;
+        c->busy[k] = false;
+        if (!hip_ok(hipEventSynchronize(c->done[k]), "hipEventSynchronize")) return false;
+        memcpy(d + pend[k].out_off, c->h_in[k], pend[k].out_len);
+        return true;
+    };
+    while (done_blocks < dst_blocks && rc == GGQ_OK) {
+        size_t nb = std::min(chunk_blocks, dst_blocks - done_blocks);
+        size_t in_len = nb * ti->elems * ib, out_len = nb * ti->bytes;
+        if (!drain(slot)) { rc = GGQ_DEVICE; break; }
+        memcpy(c->h_out[slot], s + done_blocks * ti->elems * ib, in_len);
+        hipStream_t q = c->stream[slot];
+        bool ok = hip_ok(hipMemcpyAsync(c->d_out[slot], c->h_out[slot], in_len, hipMemcpyHostToDevice, q), "H2D");
+        if (ok) {
+            rc = launch_quant_in(ty, in_ty, c->d_in[slot], c->d_out[slot], nb, c->cus, q);
+            ok = rc == GGQ_OK;
+        }
+        ok = ok && hip_ok(hipMemcpyAsync(c->h_in[slot], c->d_in[slot], out_len, hipMemcpyDeviceToHost, q), "D2H");
+        ok = ok && hip_ok(hipEventRecord(c->done[slot], q), "hipEventRecord");
+        if (!ok) { if (rc == GGQ_OK) rc = GGQ_DEVICE; break; }
+        c->busy[slot] = true;
+        pend[slot] = {done_blocks * ti->bytes, out_len};
+        done_blocks += nb;
+        slot ^= 1;
+    }
+    for (int k = 0; k < ggq_ctx::SLOTS; ++k) {
+        int kk = (slot + k) % ggq_ctx::SLOTS;
         if (rc == GGQ_OK) { if (!drain(kk)) rc = GGQ_DEVICE; }
         else { (void)hipStreamSynchronize(c->stream[kk]); c->busy[kk] = false; }
     }

@@ -1,0 +1,434 @@
+// quantize.h -- block quantizers for gfx950: the formats the reference implements
+// (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1, Q8K) and the f16 / bf16 narrowing, bit-exact
+// with the reference's Rust (QuantExt::quantize_slice, ggml-quants/src/lib.rs:121-133).
+//
+// Shape: the mirror image of the decode kernels.  One-shot grid, one tile per
+// 512-thread workgroup, two 16-byte loads per thread (4096 f32 or 8192 f16/bf16
+// elements).  A block's elements sit in G = N / EPL consecutive lanes of one wave;
+// the per-block reductions (max by magnitude, min/max, sums, the 5th-bit mask) run over
+// those lanes with xor shuffles; packed blocks are assembled in LDS and leave as
+// contiguous 16-byte stores.  Reads dominate here (4 bytes in, 0.56-1.13 out per element).
+//
+// Order sensitivity.  The reference folds a block's elements first to last:
+//   max_by_abs (structs.rs:96-100) keeps the FIRST element of maximal magnitude and its
+//   sign -- the shuffle reduction carries the lane order and resolves ties to the
+//   earlier lane; NaN elements never win (x.abs() > acc.abs() is false for NaN);
+//   min_max (structs.rs:102-107) ignores NaN; for (+0, -0) Rust leaves min/max
+//   unspecified, fixed here as -0 < +0.
+#pragma once
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace ggq {
+
+// ---- input element types ------------------------------------------------------
+struct InF32 {
+    typedef float T;
+    static constexpr uint32_t EPL = 4;
+    static __device__ __forceinline__ void load(const T *p, float (&x)[4]) {
+        float4v v = *(const float4v *)p;
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    }
+};
+// f16 / bf16 inputs are widened first (lib.rs:67-69, 82-84)
+struct InF16 {
+    typedef uint16_t T;
+    static constexpr uint32_t EPL = 8;
+    static __device__ __forceinline__ void load(const T *p, float (&x)[8]) {
+        uint4v v = *(const uint4v *)p;
+        x[0] = h2f(v.x & 0xFFFFu); x[1] = h2f(v.x >> 16); x[2] = h2f(v.y & 0xFFFFu); x[3] = h2f(v.y >> 16);
+        x[4] = h2f(v.z & 0xFFFFu); x[5] = h2f(v.z >> 16); x[6] = h2f(v.w & 0xFFFFu); x[7] = h2f(v.w >> 16);
+    }
+};
+struct InBF16 {
+    typedef uint16_t T;
+    static constexpr uint32_t EPL = 8;
+    static __device__ __forceinline__ void load(const T *p, float (&x)[8]) {
+        uint4v v = *(const uint4v *)p;
+        x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xFFFF0000u);
+        x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xFFFF0000u);
+        x[4] = __uint_as_float(v.z << 16); x[5] = __uint_as_float(v.z & 0xFFFF0000u);
+        x[6] = __uint_as_float(v.w << 16); x[7] = __uint_as_float(v.w & 0xFFFF0000u);
+    }
+};
+
+// ---- scalar helpers with the reference's semantics -------------------------------
+__device__ __forceinline__ bool is_nan(float x) { return x != x; }
+// Rust `as u8` / `as i8` on f32: saturating, NaN -> 0
+__device__ __forceinline__ uint32_t sat_u8(float x) {
+    if (!(x > 0.0f)) return 0;          // negatives, zeros and NaN
+    if (x >= 255.0f) return 255;
+    return (uint32_t)(int)x;
+}
+__device__ __forceinline__ int sat_i8(float x) {
+    if (is_nan(x)) return 0;
+    if (x <= -128.0f) return -128;
+    if (x >= 127.0f) return 127;
+    return (int)x;
+}
+// f32::min(x, c) for a non-NaN constant c: a NaN x gives c
+__device__ __forceinline__ float min_c(float x, float c) { return x < c ? x : c; }
+__device__ __forceinline__ uint32_t f2h_bits(float x) {
+    asm volatile("" : "+v"(x));   // keep the producer from being folded into the conversion
+    return (uint32_t)__half_as_ushort(__float2half_rn(x));
+}
+// total-order min / max that ignore NaN, with -0 < +0
+__device__ __forceinline__ float min_f32(float a, float b) {
+    if (is_nan(a)) return b;
+    if (is_nan(b)) return a;
+    if (a < b) return a;
+    if (b < a) return b;
+    return (__float_as_uint(a) & 0x80000000u) ? a : b;
+}
+__device__ __forceinline__ float max_f32(float a, float b) {
+    if (is_nan(a)) return b;
+    if (is_nan(b)) return a;
+    if (a > b) return a;
+    if (b > a) return b;
+    return (__float_as_uint(a) & 0x80000000u) ? b : a;
+}
+
+// ---- reductions over the G lanes of a block (G a power of two, lanes consecutive) --
+template <uint32_t G>
+__device__ __forceinline__ float group_max_by_abs(const float *x, uint32_t n) {
+    // local fold, first to last; NaN never selected (the fold starts from +0.0)
+    float best = 0.0f;
+    for (uint32_t k = 0; k < n; ++k)
+        if (fabsf(x[k]) > fabsf(best)) best = x[k];
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t m = 1; m < G; m <<= 1) {
+        float other = __shfl_xor(best, m);
+        // the partner with the lower lane number holds earlier elements
+        float early = (lane & m) ? other : best, late = (lane & m) ? best : other;
+        best = fabsf(late) > fabsf(early) ? late : early;
+    }
+    return best;
+}
+template <uint32_t G>
+__device__ __forceinline__ float group_max_abs(const float *x, uint32_t n) {
+    float m = 0.0f;
+    for (uint32_t k = 0; k < n; ++k) { float a = fabsf(x[k]); m = a > m ? a : m; }   // acc.max(|x|), NaN ignored
+#pragma unroll
+    for (uint32_t s = 1; s < G; s <<= 1) { float o = __shfl_xor(m, s); m = o > m ? o : m; }
+    return m;
+}
+template <uint32_t G>
+__device__ __forceinline__ void group_min_max(const float *x, uint32_t n, float &lo, float &hi) {
+    lo = 3.40282347e+38f; hi = -3.40282347e+38f;
+    for (uint32_t k = 0; k < n; ++k) { lo = min_f32(lo, x[k]); hi = max_f32(hi, x[k]); }
+#pragma unroll
+    for (uint32_t s = 1; s < G; s <<= 1) {
+        lo = min_f32(lo, __shfl_xor(lo, s));
+        hi = max_f32(hi, __shfl_xor(hi, s));
+    }
+}
+template <uint32_t G>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+#pragma unroll
+    for (uint32_t s = 1; s < G; s <<= 1) v |= __shfl_xor(v, s);
+    return v;
+}
+template <uint32_t G>
+__device__ __forceinline__ int group_add(int v) {
+#pragma unroll
+    for (uint32_t s = 1; s < G; s <<= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// LDS stores at 2-byte alignment
+__device__ __forceinline__ void st16(uint8_t *p, uint32_t v) { *(uint16_t *)p = (uint16_t)v; }
+__device__ __forceinline__ void st32_a2(uint8_t *p, uint32_t v) { st16(p, v); st16(p + 2, v >> 16); }
+
+// nibble formats: EPL codes q[k] of elements e0..e0+EPL-1 (e0 = gl * EPL).  Byte i of the
+// block's 16 payload bytes = code(i) | code(i + 16) << 4: the low-half lanes fetch the codes
+// of the lane G/2 above and write EPL bytes each.
+template <uint32_t EPL, uint32_t G>
+__device__ __forceinline__ void pack_nibbles(const uint32_t *q, uint32_t gl, uint8_t *payload, bool write) {
+    constexpr uint32_t W = EPL / 4;
+    uint32_t w[W];
+#pragma unroll
+    for (uint32_t j = 0; j < W; ++j)
+        w[j] = (q[4 * j] & 0xFu) | ((q[4 * j + 1] & 0xFu) << 8) | ((q[4 * j + 2] & 0xFu) << 16) | ((q[4 * j + 3] & 0xFu) << 24);
+#pragma unroll
+    for (uint32_t j = 0; j < W; ++j) {
+        uint32_t hi = __shfl_xor(w[j], G / 2);
+        if (write && gl < G / 2) st32_a2(payload + gl * EPL + 4 * j, w[j] | (hi << 4));
+    }
+}
+
+// ================================ the formats =====================================
+// Each encode() is called by all lanes of a wave; `blk` = this lane's block in LDS,
+// gl = lane within the block's group, x = this lane's EPL elements, write = block exists.
+
+// ggml-quants/src/structs/q4_0.rs:23-44
+struct EncQ4_0 {
+    static constexpr uint32_t N = 32, BYTES = 18;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float max = group_max_by_abs<G>(x, EPL);
+        uint32_t q[EPL];
+        uint32_t hdr = 0;
+        if (max == 0.0f) {
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(max, -8.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta);
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_u8(min_c(__fadd_rn(__fmul_rn(x[k], recip), 8.5f), 15.0f));
+        }
+        if (write && gl == 0) st16(blk, hdr);
+        pack_nibbles<EPL, G>(q, gl, blk + 2, write);
+    }
+};
+
+// ggml-quants/src/structs/q4_1.rs:23-47
+struct EncQ4_1 {
+    static constexpr uint32_t N = 32, BYTES = 20;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float mn, mx;
+        group_min_max<G>(x, EPL, mn, mx);
+        uint32_t q[EPL];
+        uint32_t hdr;
+        if (mn == mx) {
+            hdr = f2h_bits(mn) << 16;
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(__fsub_rn(mx, mn), 15.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
+            for (uint32_t k = 0; k < EPL; ++k) {
+                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f));
+                q[k] = v < 15 ? v : 15;
+            }
+        }
+        if (write && gl == 0) *(uint32_t *)blk = hdr;
+        pack_nibbles<EPL, G>(q, gl, blk + 4, write);
+    }
+};
+
+// ggml-quants/src/structs/q5_0.rs:26-58
+struct EncQ5_0 {
+    static constexpr uint32_t N = 32, BYTES = 22;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float max = group_max_by_abs<G>(x, EPL);
+        uint32_t q[EPL];
+        uint32_t hdr = 0, bits = 0;
+        if (max == 0.0f) {
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(max, -16.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta);
+            for (uint32_t k = 0; k < EPL; ++k) {
+                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(x[k], recip), 16.5f));
+                q[k] = v < 31 ? v : 31;
+                bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);   // element e owns bit e of qh
+            }
+        }
+        uint32_t qh = group_or<G>(bits);
+        if (write && gl == 0) { st16(blk, hdr); st32_a2(blk + 2, qh); }
+        pack_nibbles<EPL, G>(q, gl, blk + 6, write);
+    }
+};
+
+// ggml-quants/src/structs/q5_1.rs:26-62
+struct EncQ5_1 {
+    static constexpr uint32_t N = 32, BYTES = 24;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float mn, mx;
+        group_min_max<G>(x, EPL, mn, mx);
+        uint32_t q[EPL];
+        uint32_t hdr, bits = 0;
+        if (mn == mx) {
+            hdr = f2h_bits(mn) << 16;
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(__fsub_rn(mx, mn), 31.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
+            for (uint32_t k = 0; k < EPL; ++k) {
+                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f));
+                q[k] = v < 31 ? v : 31;
+                bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);
+            }
+        }
+        uint32_t qh = group_or<G>(bits);
+        if (write && gl == 0) { *(uint32_t *)blk = hdr; *(uint32_t *)(blk + 4) = qh; }
+        pack_nibbles<EPL, G>(q, gl, blk + 8, write);
+    }
+};
+
+template <uint32_t EPL>
+__device__ __forceinline__ void store_i8(const int *q, uint8_t *p) {   // p 2-byte aligned
+#pragma unroll
+    for (uint32_t j = 0; j < EPL / 4; ++j)
+        st32_a2(p + 4 * j, (uint32_t)(q[4 * j] & 0xFF) | ((uint32_t)(q[4 * j + 1] & 0xFF) << 8) |
+                               ((uint32_t)(q[4 * j + 2] & 0xFF) << 16) | ((uint32_t)(q[4 * j + 3] & 0xFF) << 24));
+}
+
+// ggml-quants/src/structs/q8_0.rs:23-41
+struct EncQ8_0 {
+    static constexpr uint32_t N = 32, BYTES = 34;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float amax = group_max_abs<G>(x, EPL);
+        int q[EPL];
+        uint32_t hdr = 0;
+        if (amax == 0.0f) {
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta);
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_i8(roundf(__fmul_rn(x[k], recip)));
+        }
+        if (write) {
+            if (gl == 0) st16(blk, hdr);
+            store_i8<EPL>(q, blk + 2 + gl * EPL);
+        }
+    }
+};
+
+// ggml-quants/src/structs/q8_1.rs:28-55 ; sum = f16(sum_i16 as f32 * delta), delta unrounded
+struct EncQ8_1 {
+    static constexpr uint32_t N = 32, BYTES = 36;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float amax = group_max_abs<G>(x, EPL);
+        int q[EPL];
+        int part = 0;
+        float delta = 0.0f;
+        const bool zero = amax == 0.0f;
+        if (zero) {
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            delta = __fdiv_rn(amax, 127.0f);
+            float recip = __fdiv_rn(1.0f, delta);
+            for (uint32_t k = 0; k < EPL; ++k) { q[k] = sat_i8(roundf(__fmul_rn(x[k], recip))); part += q[k]; }
+        }
+        int sum = group_add<G>(part);
+        if (write) {
+            if (gl == 0) *(uint32_t *)blk = zero ? 0u : (f2h_bits(delta) | (f2h_bits(__fmul_rn((float)sum, delta)) << 16));
+            store_i8<EPL>(q, blk + 4 + gl * EPL);
+        }
+    }
+};
+
+// ggml-quants/src/structs/q8_k.rs:27-54 ; reference layout delta:f16 | quants[256] | sums[16]:i16
+struct EncQ8K {
+    static constexpr uint32_t N = 256, BYTES = 290;
+    template <uint32_t EPL>
+    static __device__ __forceinline__ void encode(const float (&x)[EPL], uint32_t gl, uint8_t *blk, bool write) {
+        constexpr uint32_t G = N / EPL;
+        float max = group_max_by_abs<G>(x, EPL);
+        int q[EPL];
+        int part = 0;
+        uint32_t hdr = 0;
+        if (max == 0.0f) {
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
+        } else {
+            float delta = __fdiv_rn(max, -127.0f), recip = __fdiv_rn(1.0f, delta);
+            hdr = f2h_bits(delta);
+            for (uint32_t k = 0; k < EPL; ++k) {
+                q[k] = sat_i8(min_c(roundf(__fmul_rn(x[k], recip)), 127.0f));
+                part += q[k];
+            }
+        }
+        int sum16 = group_add<16 / EPL>(part);        // 16 consecutive elements
+        if (write) {
+            if (gl == 0) st16(blk, hdr);
+            store_i8<EPL>(q, blk + 2 + gl * EPL);
+            if ((gl & (16 / EPL - 1)) == 0) st16(blk + 258 + 2 * (gl * EPL / 16), (uint32_t)sum16 & 0xFFFFu);
+        }
+    }
+};
+
+// ---- the kernel ------------------------------------------------------------------
+template <class Q, class In>
+struct QuantGeom {
+    static constexpr uint32_t ELEMS = WG_THREADS * In::EPL * STORES_PER_THREAD;
+    static constexpr uint32_t TB = ELEMS / Q::N;
+    static constexpr uint32_t TBYTES = TB * Q::BYTES;
+    static_assert(TBYTES % 16 == 0, "tiles leave as whole 16-byte stores");
+};
+
+// src: elements (16-byte aligned), dst: packed blocks (16-byte aligned), workgroup b -> tile b
+template <class Q, class In>
+__global__ __launch_bounds__(WG_THREADS) void quant_one(const typename In::T *__restrict__ src,
+                                                        uint8_t *__restrict__ dst, uint64_t nblocks) {
+    typedef QuantGeom<Q, In> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::TBYTES];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    constexpr uint32_t LANES = Q::N / In::EPL;          // lanes per block
+    const typename In::T *in = src + t * G::ELEMS;
+    float x[STORES_PER_THREAD][In::EPL];
+#pragma unroll
+    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
+        uint32_t el = (i * WG_THREADS + tid) * In::EPL;
+        if (el / Q::N < nblk) In::load(in + el, x[i]);
+        else
+            for (uint32_t k = 0; k < In::EPL; ++k) x[i][k] = 0.0f;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
+        uint32_t el = (i * WG_THREADS + tid) * In::EPL;
+        uint32_t bt = el / Q::N;
+        Q::template encode<In::EPL>(x[i], tid % LANES, lds + bt * Q::BYTES, bt < nblk);
+    }
+    __syncthreads();
+    // packed tile -> global, 16 bytes per thread per pass; a short last tile ends in a byte tail
+    const uint32_t nbytes = nblk * Q::BYTES;
+    uint8_t *out = dst + t * G::TBYTES;
+    for (uint32_t o = tid * 16; o + 16 <= nbytes; o += WG_THREADS * 16)
+        *(uint4v *)(out + o) = *(const uint4v *)(lds + o);
+    const uint32_t tail0 = nbytes & ~15u;
+    if (tail0 + tid < nbytes) out[tail0 + tid] = lds[tail0 + tid];
+}
+
+// ---- f32 / f16 / bf16 -> f16 / bf16 (the 1-element "blocks", half.rs:10-17, 26-33) ----
+template <class In, class O>
+__global__ __launch_bounds__(WG_THREADS) void narrow_vec(const typename In::T *__restrict__ src,
+                                                         typename O::T *__restrict__ dst, uint64_t n) {
+    // n = elements, a multiple of In::EPL handled here; each thread converts EPL elements per step
+    const uint64_t base = ((uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x) * In::EPL;
+#pragma unroll
+    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
+        uint64_t el = base + (uint64_t)i * WG_THREADS * In::EPL;
+        if (el + In::EPL > n) continue;
+        float x[In::EPL];
+        In::load(src + el, x);
+        if constexpr (In::EPL == 4) {
+            uint2v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3])};
+            *(uint2v *)(dst + el) = o;
+        } else {
+            uint4v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3]), O::pk(x[4], x[5]), O::pk(x[6], x[7])};
+            *(uint4v *)(dst + el) = o;
+        }
+    }
+}
+
+template <class In, class O>
+__global__ __launch_bounds__(WG_THREADS) void narrow_scalar(const typename In::T *__restrict__ src,
+                                                            typename O::T *__restrict__ dst,
+                                                            uint64_t first, uint64_t n) {
+    uint64_t i = first + (uint64_t)blockIdx.x * WG_THREADS + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * WG_THREADS;
+    for (; i < n; i += stride) {
+        float f;
+        if constexpr (sizeof(typename In::T) == 4) f = src[i];
+        else if constexpr (std::is_same<In, InF16>::value) f = h2f(src[i]);
+        else f = __uint_as_float((uint32_t)src[i] << 16);
+        dst[i] = (uint16_t)(O::pk(f, 0.0f) & 0xFFFFu);
+    }
+}
+
+}  // namespace ggq

@@ -19,6 +19,7 @@
 
 #include "kernels.h"
 #include "kernels_v2.h"
+#include "quantize.h"
 
 using namespace ggq;
 
@@ -448,6 +449,25 @@ int main(int argc, char **argv) {
     SHIPO(Q4K, OutF32, 2, 0, 0, "mis Q4K off2 nopf")
     SHIPO(Q6K, OutF32, 0, 512, 768, "mis Q6K off0 P512 L768")
     SHIPO(Q2K, OutF32, 0, 1280, 1280, "mis Q2K off0 P1280 L1280")
+#define QNT(Q, In, LABEL)                                                                                   \
+    {                                                                                                       \
+        typedef QuantGeom<Q, In> G;                                                                         \
+        uint64_t blocks = elems / Q::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
+        double bytes = (double)elems * ((double)Q::BYTES / Q::N + sizeof(typename In::T));                  \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((quant_one<Q, In>), dim3(grid), dim3(WG_THREADS), 0, s,        \
+                                             (const typename In::T *)d_out, (uint8_t *)d_in, blocks); }, {}}); \
+    }
+    QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
+    QNT(EncQ4_1, InF32, "quant Q4_1 from f32")
+    QNT(EncQ5_0, InF32, "quant Q5_0 from f32")
+    QNT(EncQ5_1, InF32, "quant Q5_1 from f32")
+    QNT(EncQ8_0, InF32, "quant Q8_0 from f32")
+    QNT(EncQ8_1, InF32, "quant Q8_1 from f32")
+    QNT(EncQ8K, InF32, "quant Q8K from f32")
+    QNT(EncQ8_0, InF16, "quant Q8_0 from f16")
+    QNT(EncQ4_0, InBF16, "quant Q4_0 from bf16")
     SHIP(Q4K, OutF32, "ship Q4K f32")
     SHIP(Q6K, OutF32, "ship Q6K f32")
     SHIP(Q2K, OutF32, "ship Q2K f32")

@@ -114,6 +114,12 @@ template <class Blk, class T> struct QuantExt {
         return to_result(ggq_dequantize_slice(DataBlock<Blk>::ID, OutType<T>::ID, dst.ptr, dst.len,
                                               src.ptr, src.len));
     }
+    /// lib.rs:121-133.  Implemented for the blocks the reference implements
+    /// (f16, bf16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1, Q8K); others give Unsupported.
+    static Result quantize_slice(Slice<Blk> dst, Slice<const T> src) {
+        return to_result(ggq_quantize_slice(DataBlock<Blk>::ID, OutType<T>::ID, dst.ptr, dst.len,
+                                            src.ptr, src.len));
+    }
     /// Device slices on the current HIP device; enqueued on `hip_stream`, not synchronized.
     static Result dequantize_slice_device(Slice<T> dst, Slice<const Blk> src, void *hip_stream = nullptr) {
         return to_result(ggq_dequantize_device(DataBlock<Blk>::ID, OutType<T>::ID, dst.ptr, dst.len,

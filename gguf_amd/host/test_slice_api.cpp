@@ -56,7 +56,28 @@ int main(int argc, char **argv) {
         auto r = QuantExt<Q8_0, float>::dequantize_slice({out.data(), out.size()}, {src.data(), src.size()});
         CHECK(r && *r == QuantizeError::Indivisible);
     }
+    {   // test_quant_slice_indivisible (lib.rs:293-301)
+        std::vector<float> in(N - 1);
+        std::vector<Q8_0> q(1);
+        auto r = QuantExt<Q8_0, float>::quantize_slice({q.data(), q.size()}, {in.data(), in.size()});
+        CHECK(r && *r == QuantizeError::Indivisible);
+    }
+    {   // test_quant_slice_length_mismatch (lib.rs:303-311)
+        std::vector<float> in(2 * N);
+        std::vector<Q8_0> q(3);
+        auto r = QuantExt<Q8_0, float>::quantize_slice({q.data(), q.size()}, {in.data(), in.size()});
+        CHECK(r && *r == QuantizeError::LengthMismatch);
+    }
     if (device) {
+        {   // quantize on the device, then decode: test_quant_dequant_slice_ok (lib.rs:276-291)
+            std::vector<float> in(2 * N), out(2 * N);
+            for (size_t i = 0; i < in.size(); ++i) in[i] = std::cos(0.41f * (float)i) * 0.95f;
+            std::vector<Q8_0> q(2);
+            auto r1 = QuantExt<Q8_0, float>::quantize_slice({q.data(), q.size()}, {in.data(), in.size()});
+            auto r2 = QuantExt<Q8_0, float>::dequantize_slice({out.data(), out.size()}, {q.data(), q.size()});
+            CHECK(!r1 && !r2);
+            for (size_t i = 0; i < in.size(); ++i) CHECK(std::fabs(in[i] - out[i]) < 4.5e-3f);
+        }
         {   // test_block_zeros_and_count (lib.rs:333-338)
             std::vector<Q8_0> src(2);
             std::memset(src.data(), 0, sizeof(Q8_0) * 2);

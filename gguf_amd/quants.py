@@ -176,6 +176,36 @@ def dequantize_slice(ty, dst, src, stream=None):
         check(lib.ggq_dequantize_slice(int(ty), int(out_ty), dp, dn, sp, blocks))
 
 
+def quantize_slice(ty, dst, src, stream=None):
+    """QuantExt::quantize_slice (ggml-quants/src/lib.rs:121-133) for block type `ty`.
+
+    `src`: elements (float32, float16 or bfloat16); `dst`: uint8 buffer that receives the
+    packed blocks, len(dst) / block_bytes(ty) blocks.
+    """
+    ty = GGmlType(int(ty))
+    bb = block_bytes(ty)
+    if bb == 0:
+        raise Unsupported()
+    sp, sn, _, s_dev = _describe(src)
+    dp, dn, ds, d_dev = _describe(dst)
+    nbytes = dn * ds
+    if nbytes % bb:
+        raise ValueError(f"{nbytes} bytes is not a whole number of {bb}-byte blocks")
+    blocks = nbytes // bb
+    in_ty = _out_type(src)
+    if s_dev != d_dev:
+        raise ValueError("src and dst must both be on the device or both on the host")
+    if s_dev:
+        import torch
+        if src.device != dst.device:
+            raise ValueError("src and dst are on different devices")
+        with torch.cuda.device(dst.device):
+            st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+            check(lib.ggq_quantize_device(int(ty), int(in_ty), dp, blocks, sp, sn, st))
+    else:
+        check(lib.ggq_quantize_slice(int(ty), int(in_ty), dp, blocks, sp, sn))
+
+
 class _Block:
     """DataBlock (ggml-quants/src/lib.rs:11-21) + QuantExt for one block type."""
     TYPE = None
@@ -195,6 +225,10 @@ class _Block:
     @classmethod
     def dequantize_slice(cls, dst, src, stream=None):
         return dequantize_slice(cls.TYPE, dst, src, stream)
+
+    @classmethod
+    def quantize_slice(cls, dst, src, stream=None):
+        return quantize_slice(cls.TYPE, dst, src, stream)
 
 
 def _mk(name, ty):

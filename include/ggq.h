@@ -97,6 +97,27 @@ ggq_status ggq_dequantize_device(uint32_t ggml_type, uint32_t out_type,
                                  const void *d_src, size_t src_blocks,
                                  void *hip_stream);
 
+/* ---- quantize -------------------------------------------------------------
+ * Replaces `<Blk as QuantExt<T, N>>::quantize_slice(dst: &mut [Blk], src: &[T])`
+ * (ggml-quants/src/lib.rs:121-133) for the block types the reference implements:
+ * F16, BF16 (1-element blocks, structs/half.rs:8-38), Q4_0, Q4_1, Q5_0, Q5_1, Q8_0,
+ * Q8_1 and Q8K.  `in_type` selects T: F32 (0), F16 (1) or BF16 (30); 16-bit inputs
+ * are widened first, as lib.rs:67-69 / 82-84 do.  Every other target type returns
+ * GGQ_UNSUPPORTED (`todo!()` in the reference).  Checks, in the reference's order:
+ * src_elems % N -> GGQ_INDIVISIBLE, then dst_blocks != src_elems / N ->
+ * GGQ_LENGTH_MISMATCH.  Output bytes equal the reference's for the same input; where
+ * Rust leaves the result open (f32::min / max of +0 and -0) the rule is -0 < +0.
+ * Host form: any alignment, synchronous, staged through the same per-device pipeline
+ * pool as ggq_dequantize_slice.  Device form: d_src and d_dst 16-byte aligned
+ * (GGQ_MISALIGNED otherwise), enqueued on `hip_stream`, not synchronized. */
+ggq_status ggq_quantize_slice(uint32_t ggml_type, uint32_t in_type,
+                              void *dst, size_t dst_blocks,
+                              const void *src, size_t src_elems);
+ggq_status ggq_quantize_device(uint32_t ggml_type, uint32_t in_type,
+                               void *d_dst, size_t dst_blocks,
+                               const void *d_src, size_t src_elems,
+                               void *hip_stream);
+
 /* ---- dequantize, batch of device-resident tensors -------------------------
  * One call decodes many tensors (a whole model's tensor table) with one kernel
  * launch per block type present, instead of one per tensor.  Stands in for the

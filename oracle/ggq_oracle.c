@@ -562,11 +562,30 @@ static float max_by_abs(const float *x, int n)
     for (int i = 0; i < n; ++i) if (fabsf(x[i]) > fabsf(acc)) acc = x[i];
     return acc;
 }
+/* f32::min / f32::max: a NaN operand is ignored.  For (+0, -0) Rust leaves the
+ * result unspecified (llvm.minnum / maxnum); it is fixed here as -0 < +0, which makes
+ * the fold independent of the order of the elements. */
+static inline float min_f32(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a < b) return a;
+    if (b < a) return b;
+    return (f32_bits(a) & 0x80000000u) ? a : b;
+}
+static inline float max_f32(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a > b) return a;
+    if (b > a) return b;
+    return (f32_bits(a) & 0x80000000u) ? b : a;
+}
 /* structs.rs:102-107 */
 static void min_max(const float *x, int n, float *mn, float *mx)
 {
     float lo = 3.40282347e+38f, hi = -3.40282347e+38f;
-    for (int i = 0; i < n; ++i) { lo = fminf(lo, x[i]); hi = fmaxf(hi, x[i]); }
+    for (int i = 0; i < n; ++i) { lo = min_f32(lo, x[i]); hi = max_f32(hi, x[i]); }
     *mn = lo; *mx = hi;
 }
 

@@ -1,0 +1,189 @@
+"""Parity of the GPU quantizers with the CPU oracle, through the C ABI: packed bytes
+must be identical (integer codes, f16 headers, Q8_1 / Q8K sums)."""
+import numpy as np
+import pytest
+
+from util import same_bits
+
+pytestmark = pytest.mark.gpu
+
+QUANT = [2, 3, 6, 7, 8, 9, 15]          # Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q8_1 Q8K
+IN = {"f32": 0, "f16": 1, "bf16": 30}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def to_in(oracle, x, kind):
+    """float32 values -> the array handed to the quantizer (uint16 patterns for 16-bit inputs)."""
+    if kind == "f32":
+        return x
+    return oracle.quantize(oracle.F16 if kind == "f16" else oracle.BF16, x).view(np.uint16)
+
+
+def gpu_quantize(torch, ty, arr, kind):
+    import gguf_amd as g
+    n = arr.size
+    blocks = n // g.block_elems(ty)
+    if kind == "f32":
+        src = torch.from_numpy(arr).cuda()
+    else:
+        dt = torch.float16 if kind == "f16" else torch.bfloat16
+        src = torch.from_numpy(arr.view(np.int16)).cuda().view(dt)
+    dst = torch.full((blocks * g.block_bytes(ty) + 16,), 0xAB, dtype=torch.uint8, device="cuda")
+    g.quantize_slice(ty, dst[: blocks * g.block_bytes(ty)], src)
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    assert (out[blocks * g.block_bytes(ty):] == 0xAB).all(), "wrote past the end"
+    return out[: blocks * g.block_bytes(ty)]
+
+
+def check(oracle, ty, got, arr, kind):
+    want = oracle.quantize(ty, arr, in_ty=IN[kind])
+    if not np.array_equal(got, want):
+        bb = oracle.block_bytes(ty)
+        bad = np.nonzero(got != want)[0]
+        b = int(bad[0]) // bb
+        raise AssertionError(f"type {ty} in {kind}: {bad.size} bytes differ, first in block {b} at byte "
+                             f"{int(bad[0]) % bb}: got {got[b*bb:(b+1)*bb].tolist()} want {want[b*bb:(b+1)*bb].tolist()}")
+
+
+@pytest.mark.parametrize("ty", QUANT)
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_random_blocks(torch_cuda, oracle, ty, kind):
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(100 + ty)
+    tile = 4096 if kind == "f32" else 8192
+    for blocks in (1, 2, tile // n - 1, tile // n, tile // n + 1, 5 * tile // n + 3):
+        x = (rng.standard_normal(blocks * n) * rng.choice([1e-3, 0.02, 1.0, 300.0])).astype(np.float32)
+        arr = to_in(oracle, x, kind)
+        check(oracle, ty, gpu_quantize(torch_cuda, ty, arr, kind), arr, kind)
+
+
+@pytest.mark.parametrize("ty", QUANT)
+def test_uniform_01_like_the_reference_tests(torch_cuda, oracle, ty):
+    """U[0,1) blocks as in lib.rs:173-194, then the reference's tolerance on the GPU round trip."""
+    import gguf_amd as g
+    n = oracle.block_elems(ty)
+    tol = {2: 8e-2, 3: 4e-2, 6: 4e-2, 7: 2e-2, 8: 4.5e-3, 9: 4.5e-3, 15: 4.5e-3}[ty]
+    x = np.random.default_rng(ty).random(300 * n, dtype=np.float32)
+    packed = gpu_quantize(torch_cuda, ty, x, "f32")
+    check(oracle, ty, packed, x, "f32")
+    t = torch_cuda
+    dst = t.empty(x.size, dtype=t.float32, device="cuda")
+    g.dequantize_slice(ty, dst, t.from_numpy(packed).cuda())
+    assert float(np.max(np.abs(dst.cpu().numpy() - x))) <= tol
+
+
+@pytest.mark.parametrize("ty", QUANT)
+def test_order_and_tie_rules(torch_cuda, oracle, ty):
+    """max_by_abs keeps the first element of maximal magnitude and its sign; zero blocks;
+    all-equal blocks (min == max); signed zeros; values that clamp."""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(7)
+    rows = []
+    base = rng.standard_normal(n).astype(np.float32)
+    for first, second in ((3, n - 2), (n - 2, 3), (0, n - 1), (n // 2 - 1, n // 2)):
+        for s1, s2 in ((1, -1), (-1, 1)):
+            r = base.copy() * 0.1
+            r[first], r[second] = s1 * 2.5, s2 * 2.5       # equal magnitudes, opposite signs
+            rows.append(r)
+    rows.append(np.zeros(n, dtype=np.float32))
+    rows.append(np.full(n, -0.0, dtype=np.float32))
+    z = np.zeros(n, dtype=np.float32); z[1::2] = -0.0
+    rows.append(z)
+    rows.append(np.full(n, 0.7311, dtype=np.float32))                   # min == max
+    rows.append(np.full(n, -3.0, dtype=np.float32))
+    r = base.copy(); r[5] = 1e30; rows.append(r)                         # huge outlier
+    r = base.copy() * 1e-30; rows.append(r)                              # tiny values (f16 delta underflows)
+    r = base.copy() * 1e-42; rows.append(r)                              # f32 subnormals
+    r = np.linspace(-1, 1, n).astype(np.float32); rows.append(r)
+    r = np.linspace(1, -1, n).astype(np.float32); rows.append(r)
+    x = np.concatenate(rows)
+    for kind in ("f32", "f16", "bf16"):
+        arr = to_in(oracle, x, kind)
+        check(oracle, ty, gpu_quantize(torch_cuda, ty, arr, kind), arr, kind)
+
+
+@pytest.mark.parametrize("ty", [2, 3, 6, 7, 8, 15])
+def test_nan_elements_are_ignored_by_the_folds(torch_cuda, oracle, ty):
+    """NaN never wins max_by_abs / min / max; its own code comes from the saturating cast
+    (NaN -> 0, or 15 / 31 / 127 after `.min(c)`).  Q8_1 is left out: its `sum` header is
+    0 * inf-free only without infinities, and the default NaN differs between x86 and the GPU."""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(6 * n).astype(np.float32)
+    x[3] = np.nan; x[n + 0] = np.nan; x[2 * n + n - 1] = np.nan
+    x[3 * n: 4 * n] = np.nan                       # a block of nothing but NaN
+    x[4 * n + 7] = np.nan; x[4 * n + 8] = -np.nan
+    check(oracle, ty, gpu_quantize(torch_cuda, ty, x, "f32"), x, "f32")
+
+
+@pytest.mark.parametrize("ty,kind", [(1, "f32"), (30, "f32"), (30, "f16"), (1, "bf16"), (1, "f16"), (30, "bf16")])
+def test_narrowing(torch_cuda, oracle, ty, kind):
+    """f16::from_f32 / bf16::from_f32 per element (half.rs:10-17, 26-33), incl. ties and specials."""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(70001) * np.float32(10.0) ** rng.integers(-9, 6, 70001)).astype(np.float32)
+    h = np.arange(0x7C00, dtype=np.uint16).view(np.float16).astype(np.float64)
+    mid = ((h[:-1] + h[1:]) / 2).astype(np.float32)
+    x = np.concatenate([x, mid, -mid, np.array([0, -0.0, 65504, 65520, 1e-8, np.inf, -np.inf, 1e38], dtype=np.float32)])
+    arr = to_in(oracle, x, kind)
+    got = gpu_quantize(torch_cuda, ty, arr, kind).view(np.uint16)
+    want = oracle.quantize(ty, arr, in_ty=IN[kind]).view(np.uint16)
+    assert np.array_equal(got, want)
+
+
+def test_slice_errors(torch_cuda):
+    """lib.rs:293-311 through the device entry point."""
+    import gguf_amd as g
+    t = torch_cuda
+    src = t.zeros(64, dtype=t.float32, device="cuda")
+    dst = t.zeros(34 * 3, dtype=t.uint8, device="cuda")
+    with pytest.raises(g.Indivisible):
+        g.Q8_0.quantize_slice(dst[:34], src[:31])
+    with pytest.raises(g.LengthMismatch):
+        g.Q8_0.quantize_slice(dst, src)
+    with pytest.raises(g.Indivisible):
+        g.Q8_0.quantize_slice(dst, src[:31])
+    with pytest.raises(g.Unsupported):
+        g.Q4K.quantize_slice(t.zeros(144, dtype=t.uint8, device="cuda"), t.zeros(256, dtype=t.float32, device="cuda"))
+    g.Q8_0.quantize_slice(dst[:68], src)           # zeros -> ZEROS blocks (lib.rs:333-338)
+    t.cuda.synchronize()
+    assert not dst[:68].cpu().numpy().any()
+
+
+@pytest.mark.parametrize("ty", [8, 2, 15])
+def test_host_entry_point(torch_cuda, oracle, ty):
+    import gguf_amd as g
+    n = oracle.block_elems(ty)
+    blocks = (9 << 20) // n + 5
+    x = (np.random.default_rng(5).standard_normal(blocks * n) * 0.02).astype(np.float32)
+    hold = np.zeros(x.size + 1, dtype=np.float32)[1:]   # 4-byte, not 16-byte, aligned
+    hold[:] = x
+    dst = np.zeros(blocks * oracle.block_bytes(ty) + 1, dtype=np.uint8)
+    g.quantize_slice(ty, dst[1:], hold)
+    assert np.array_equal(dst[1:], oracle.quantize(ty, x))
+
+
+def test_tinyllama_f16_to_q8_0_round_trip(torch_cuda, oracle):
+    """BASELINE config 0 on the GPU: F16 tensor -> Q8_0 -> F32, on one TinyLlama-shaped
+    tensor (attn_output [2048, 2048]) with seeded F16 payload (the shipped file has none)."""
+    import gguf_amd as g
+    t = torch_cuda
+    rng = np.random.default_rng(0xC0FFEE01)
+    w16 = (rng.standard_normal(2048 * 2048) * 0.02).astype(np.float16)
+    src = t.from_numpy(w16.view(np.int16)).cuda().view(t.float16)
+    q = t.empty(w16.size // 32 * 34, dtype=t.uint8, device="cuda")
+    g.Q8_0.quantize_slice(q, src)
+    out = t.empty(w16.size, dtype=t.float32, device="cuda")
+    g.Q8_0.dequantize_slice(out, q)
+    t.cuda.synchronize()
+    want_q = oracle.quantize(8, w16.view(np.uint16), in_ty=oracle.F16)
+    assert np.array_equal(q.cpu().numpy(), want_q)
+    want = oracle.dequantize(8, want_q, threads=8)
+    assert same_bits(out.cpu().numpy(), want)
+    assert float(np.max(np.abs(want - w16.astype(np.float32)))) < 4.5e-3
