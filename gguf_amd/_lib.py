@@ -26,7 +26,24 @@ class ggq_tensor(ctypes.Structure):
                 ("blocks", ctypes.c_uint64)]
 
 
-# every symbol include/ggq.h declares: name -> (restype, argtypes)
+class ggq_gguf_info(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint32), ("tensor_count", ctypes.c_uint64), ("kv_count", ctypes.c_uint64),
+                ("alignment", ctypes.c_uint64), ("data_offset", ctypes.c_uint64), ("data_len", ctypes.c_uint64),
+                ("data_avail", ctypes.c_uint64)]
+
+
+class ggq_gguf_tensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_void_p), ("name_len", ctypes.c_size_t), ("ggml_type", ctypes.c_uint32),
+                ("ndim", ctypes.c_uint32), ("shape", ctypes.c_uint64 * 4), ("offset", ctypes.c_uint64),
+                ("nbytes", ctypes.c_uint64), ("data", ctypes.c_void_p)]
+
+
+class ggq_gguf_kv(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_void_p), ("key_len", ctypes.c_size_t), ("type", ctypes.c_uint32),
+                ("value", ctypes.c_void_p), ("value_len", ctypes.c_size_t)]
+
+
+# every symbol include/ggq.h and include/ggq_gguf.h declare: name -> (restype, argtypes)
 _vp, _sz, _u32, _int = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
 SYMBOLS = {
     "ggq_block_elems": (_sz, [_u32]),
@@ -49,6 +66,18 @@ SYMBOLS = {
     "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),
     "ggq_sync": (_int, [_vp]),
     "ggq_ctx_destroy": (None, [_vp]),
+    "ggq_gguf_parse": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "ggq_gguf_open": (_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "ggq_gguf_close": (None, [_vp]),
+    "ggq_gguf_last_name": (ctypes.c_char_p, []),
+    "ggq_gguf_error_str": (ctypes.c_char_p, [_int]),
+    "ggq_gguf_get_info": (_int, [_vp, ctypes.POINTER(ggq_gguf_info)]),
+    "ggq_gguf_tensor_at": (_int, [_vp, _sz, ctypes.POINTER(ggq_gguf_tensor)]),
+    "ggq_gguf_find_tensor": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ggq_gguf_tensor)]),
+    "ggq_gguf_kv_at": (_int, [_vp, _sz, ctypes.POINTER(ggq_gguf_kv)]),
+    "ggq_gguf_find_kv": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ggq_gguf_kv)]),
+    "ggq_gguf_type_bytes": (_sz, [_u32]),
+    "ggq_gguf_type_elems": (_sz, [_u32]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -1,0 +1,261 @@
+"""GGUF container access: host-side mirror of the reference's `ggus` reader over the C ABI of
+include/ggq_gguf.h (`GGuf::new`, ggus/src/file.rs:66-145), a minimal writer for building files
+(layout of ggus/src/write/writer.rs:95-128: header, key/values, tensor infos, padding, data), and
+the whole-file decode that the reference's `convert ... -x cast:...:f32` performs one tensor at a
+time (xtask/src/utils/operator/cast.rs:73-90).
+"""
+import ctypes
+import struct
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+from .quants import GGmlType, block_bytes, block_elems
+
+OK = 0
+ERRORS = {1: "Eos", 2: "Utf8", 3: "Bool", 4: "MagicMismatch", 5: "EndianNotSupport", 6: "VersionNotSupport",
+          7: "AlignmentTypeMismatch", 8: "DuplicateMetaKey", 9: "DuplicateTensorName", 10: "Io",
+          11: "ValueType", 12: "NotFound", 13: "Invalid"}
+DEFAULT_ALIGNMENT = 32
+
+_SCALAR = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 6: "<f", 7: "<?", 10: "<Q", 11: "<q", 12: "<d"}
+
+
+class GGufError(Exception):
+    """GGufError / GGufReadError of the reference (file.rs:25-40, read.rs:14-21)."""
+
+    def __init__(self, code, name=""):
+        self.code = code
+        self.kind = ERRORS.get(code, str(code))
+        self.name = name
+        super().__init__(lib.ggq_gguf_error_str(code).decode() + (f": {name}" if name else ""))
+
+
+def _check(code):
+    if code != OK:
+        name = lib.ggq_gguf_last_name().decode() if code in (7, 8, 9) else ""
+        raise GGufError(code, name)
+
+
+class TensorInfo:
+    """GGufTensorInfo (ggus/src/tensor.rs:255-290) plus where its bytes are."""
+    __slots__ = ("name", "ty", "shape", "offset", "nbytes", "ptr")
+
+    def __init__(self, t):
+        self.name = ctypes.string_at(t.name, t.name_len).decode()
+        self.ty = t.ggml_type
+        self.shape = tuple(t.shape[i] for i in range(min(t.ndim, 4)))
+        self.offset = t.offset
+        self.nbytes = t.nbytes
+        self.ptr = t.data                  # None when the file does not hold the tensor
+
+    def bytes(self):
+        """Zero-copy uint8 view of the packed data (valid while the GGuf is open)."""
+        if not self.ptr:
+            raise ValueError(f"{self.name}: the file holds no data for this tensor")
+        return np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(self.nbytes,))
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def _decode_value(ty, buf, pos=0):
+    if ty in _SCALAR:
+        return struct.unpack_from(_SCALAR[ty], buf, pos)[0], pos + struct.calcsize(_SCALAR[ty])
+    if ty == 8:
+        n = struct.unpack_from("<Q", buf, pos)[0]
+        return bytes(buf[pos + 8:pos + 8 + n]).decode("utf-8"), pos + 8 + n
+    if ty == 9:
+        ety, n = struct.unpack_from("<IQ", buf, pos)
+        pos += 12
+        out = []
+        for _ in range(n):
+            v, pos = _decode_value(ety, buf, pos)
+            out.append(v)
+        return out, pos
+    raise ValueError(f"unknown metadata value type {ty}")
+
+
+class GGuf:
+    """A parsed GGUF file.  `GGuf(path)` maps the file; `GGuf.from_bytes(buf)` parses memory."""
+
+    def __init__(self, path=None, _buf=None):
+        h = ctypes.c_void_p()
+        if _buf is not None:
+            self._keep = np.frombuffer(_buf, dtype=np.uint8) if not isinstance(_buf, np.ndarray) else _buf
+            _check(lib.ggq_gguf_parse(self._keep.ctypes.data, self._keep.size, ctypes.byref(h)))
+        else:
+            self._keep = None
+            _check(lib.ggq_gguf_open(str(path).encode(), ctypes.byref(h)))
+        self._h = h
+        info = _lib.ggq_gguf_info()
+        _check(lib.ggq_gguf_get_info(h, ctypes.byref(info)))
+        self.version = info.version
+        self.alignment = info.alignment
+        self.data_offset = info.data_offset
+        self.data_len = info.data_len
+        self.data_avail = info.data_avail
+        self.tensors = []
+        t = _lib.ggq_gguf_tensor()
+        for i in range(info.tensor_count):
+            _check(lib.ggq_gguf_tensor_at(h, i, ctypes.byref(t)))
+            self.tensors.append(TensorInfo(t))
+        self._kv_count = info.kv_count
+
+    @classmethod
+    def from_bytes(cls, buf):
+        return cls(_buf=buf)
+
+    def meta_raw(self, key):
+        """(value type, raw value bytes) like GGufMetaMap::get (file.rs:58-62); None if absent."""
+        kv = _lib.ggq_gguf_kv()
+        code = lib.ggq_gguf_find_kv(self._h, key.encode(), ctypes.byref(kv))
+        if code == 12:
+            return None
+        _check(code)
+        return kv.type, ctypes.string_at(kv.value, kv.value_len)
+
+    def meta(self, key, default=None):
+        raw = self.meta_raw(key)
+        if raw is None:
+            return default
+        return _decode_value(raw[0], raw[1])[0]
+
+    def keys(self):
+        kv = _lib.ggq_gguf_kv()
+        out = []
+        for i in range(self._kv_count):
+            _check(lib.ggq_gguf_kv_at(self._h, i, ctypes.byref(kv)))
+            out.append(ctypes.string_at(kv.key, kv.key_len).decode())
+        return out
+
+    def tensor(self, name):
+        t = _lib.ggq_gguf_tensor()
+        _check(lib.ggq_gguf_find_tensor(self._h, name.encode(), ctypes.byref(t)))
+        return TensorInfo(t)
+
+    def close(self):
+        if self._h:
+            lib.ggq_gguf_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- writer --------------------------------------------------------------------------------
+
+def _enc_str(s):
+    b = s.encode("utf-8")
+    return struct.pack("<Q", len(b)) + b
+
+
+def _enc_value(v):
+    """(type id, bytes) for a Python value: bool, int (-> u32 / i32 / u64 / i64), float (f32), str,
+    or a (type id, value) pair to force a type; lists become arrays of their first item's type."""
+    if isinstance(v, tuple):
+        ty, val = v
+        if ty in _SCALAR:
+            return ty, struct.pack(_SCALAR[ty], val)
+        if ty == 8:
+            return 8, _enc_str(val)
+        raise ValueError(ty)
+    if isinstance(v, bool):
+        return 7, struct.pack("<?", v)
+    if isinstance(v, int):
+        if 0 <= v < 2 ** 32:
+            return 4, struct.pack("<I", v)
+        if -2 ** 31 <= v < 0:
+            return 5, struct.pack("<i", v)
+        return (10, struct.pack("<Q", v)) if v >= 0 else (11, struct.pack("<q", v))
+    if isinstance(v, float):
+        return 6, struct.pack("<f", v)
+    if isinstance(v, str):
+        return 8, _enc_str(v)
+    if isinstance(v, (list, tuple)):
+        items = [_enc_value(x) for x in v]
+        ety = items[0][0] if items else 4
+        return 9, struct.pack("<IQ", ety, len(items)) + b"".join(b for _, b in items)
+    raise TypeError(type(v))
+
+
+def build_gguf(meta, tensors, alignment=None, with_data=True):
+    """Bytes of a GGUF v3 file.  meta: {key: value}; tensors: [(name, ggml_type, shape, data)], data a
+    uint8 array of exactly the tensor's packed bytes (or None with with_data=False for a
+    metadata-only file like the reference's test asset)."""
+    meta = dict(meta)
+    if alignment is not None:
+        meta["general.alignment"] = alignment
+    align = int(meta.get("general.alignment", DEFAULT_ALIGNMENT)
+                if not isinstance(meta.get("general.alignment"), tuple) else meta["general.alignment"][1])
+    out = bytearray(b"GGUF" + struct.pack("<IQQ", 3, len(tensors), len(meta)))
+    for k, v in meta.items():
+        ty, b = _enc_value(v)
+        out += _enc_str(k) + struct.pack("<I", ty) + b
+    offset = 0
+    offsets = []
+    for name, ty, shape, data in tensors:
+        eb, ee = lib.ggq_gguf_type_bytes(int(ty)), lib.ggq_gguf_type_elems(int(ty))
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n // ee * eb
+        if data is not None:
+            assert np.asarray(data).nbytes == nbytes, (name, np.asarray(data).nbytes, nbytes)
+        out += _enc_str(name) + struct.pack("<I", len(shape)) + b"".join(struct.pack("<Q", s) for s in shape)
+        out += struct.pack("<IQ", int(ty), offset)
+        offsets.append((offset, nbytes))
+        offset += nbytes + (-nbytes) % align
+    if with_data and tensors:
+        out += b"\0" * ((-len(out)) % align)
+        base = len(out)
+        for (name, ty, shape, data), (off, nbytes) in zip(tensors, offsets):
+            out += b"\0" * (base + off - len(out))
+            out += np.ascontiguousarray(data).view(np.uint8).tobytes()
+    return bytes(out)
+
+
+# ---- whole-file decode ---------------------------------------------------------------------
+
+def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None):
+    """Decode every tensor of an open GGuf that holds data and has a block type this library
+    decodes, streamed host -> device through one Context; returns {name: device tensor}.
+    F32 tensors are copied as they are (the reference's cast leaves them alone too)."""
+    import torch
+    from .quants import Context, SUPPORTED
+    dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out]
+    ctx = Context(device, staging_bytes)
+    res = {}
+    try:
+        with torch.cuda.device(device):
+            for t in gguf.tensors:
+                if only is not None and t.name not in only:
+                    continue
+                if not t.ptr:
+                    continue
+                if t.ty == GGmlType.F32:
+                    res[t.name] = torch.from_numpy(t.bytes().view(np.float32).copy()).to(f"cuda:{device}")
+                    continue
+                if t.ty not in [int(x) for x in SUPPORTED]:
+                    continue
+                dst = torch.empty(t.numel, dtype=dt, device=f"cuda:{device}")
+                ctx.dequantize_async(t.ty, dst, t.bytes())
+                res[t.name] = dst
+            ctx.sync()
+    finally:
+        ctx.close()
+    return res

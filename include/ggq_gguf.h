@@ -1,0 +1,111 @@
+/*
+ * ggq_gguf.h -- C ABI of the GGUF container reader in libggq.
+ *
+ * Replaces the zero-copy v3 parser of the reference crate `ggus`:
+ *   GGuf::new(&[u8])              ggus/src/file.rs:66-145
+ *   GGufReader primitives          ggus/src/read.rs:23-91
+ *   header                         ggus/src/header.rs:7-57
+ *   meta key/value skip-scan       ggus/src/metadata/meta_kv.rs:12-54
+ *   tensor meta / info             ggus/src/tensor.rs:191-290
+ * and the mmap of input files (xtask/src/utils/mod.rs:42-46).  It feeds the
+ * dequantize entry points of ggq.h with (type, shape, pointer) for each tensor.
+ * Nothing is copied: every pointer handed out points into the caller's buffer
+ * (ggq_gguf_parse) or into the file mapping (ggq_gguf_open) and is valid until
+ * ggq_gguf_close.
+ *
+ * One deliberate difference: a file whose tensor data is shorter than its tensor
+ * table says (the reference's own test asset is metadata-only) parses fine here;
+ * tensors the file does not hold have data == NULL.  The reference panics on it
+ * (slice out of range at file.rs:130-135).
+ */
+#ifndef GGQ_GGUF_H
+#define GGQ_GGUF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* GGufError (file.rs:25-40) with GGufReadError (read.rs:14-21) flattened in. */
+typedef enum ggq_gguf_error {
+    GGQ_GGUF_OK = 0,
+    GGQ_GGUF_EOS = 1,              /* Reading(Eos): the data ends inside a field          */
+    GGQ_GGUF_UTF8 = 2,             /* Reading(Utf8): a string is not valid UTF-8          */
+    GGQ_GGUF_BOOL = 3,             /* Reading(Bool): a bool byte is neither 0 nor 1       */
+    GGQ_GGUF_MAGIC = 4,            /* MagicMismatch                                       */
+    GGQ_GGUF_ENDIAN = 5,           /* EndianNotSupport                                    */
+    GGQ_GGUF_VERSION = 6,          /* VersionNotSupport (only version 3)                  */
+    GGQ_GGUF_ALIGNMENT_TYPE = 7,   /* AlignmentTypeMismatch: general.alignment not u32/u64 */
+    GGQ_GGUF_DUP_KEY = 8,          /* DuplicateMetaKey                                    */
+    GGQ_GGUF_DUP_TENSOR = 9,       /* DuplicateTensorName                                 */
+    GGQ_GGUF_IO = 10,              /* open / fstat / mmap failed (ggq_gguf_open only)     */
+    GGQ_GGUF_VALUE_TYPE = 11,      /* unknown metadata value type id                      */
+    GGQ_GGUF_NOT_FOUND = 12,       /* no such key / tensor / index                        */
+    GGQ_GGUF_INVALID = 13          /* null argument                                       */
+} ggq_gguf_error;
+
+/* GGufMetaDataValueType (ggus/src/metadata/mod.rs) */
+enum {
+    GGQ_META_U8 = 0, GGQ_META_I8 = 1, GGQ_META_U16 = 2, GGQ_META_I16 = 3, GGQ_META_U32 = 4,
+    GGQ_META_I32 = 5, GGQ_META_F32 = 6, GGQ_META_BOOL = 7, GGQ_META_STRING = 8, GGQ_META_ARRAY = 9,
+    GGQ_META_U64 = 10, GGQ_META_I64 = 11, GGQ_META_F64 = 12
+};
+
+typedef struct ggq_gguf ggq_gguf;
+
+typedef struct ggq_gguf_info {
+    uint32_t version;
+    uint64_t tensor_count;
+    uint64_t kv_count;
+    uint64_t alignment;     /* general.alignment, default 32 (ggus/src/metadata/mod.rs:13) */
+    uint64_t data_offset;   /* offset of the tensor data region in the file / buffer       */
+    uint64_t data_len;      /* bytes the tensor table needs: max(offset + nbytes)          */
+    uint64_t data_avail;    /* bytes actually present after data_offset                    */
+} ggq_gguf_info;
+
+typedef struct ggq_gguf_tensor {
+    const char *name;       /* not NUL-terminated */
+    size_t name_len;
+    uint32_t ggml_type;     /* GGmlType discriminant */
+    uint32_t ndim;          /* at most 4 dimensions are reported in shape[] */
+    uint64_t shape[4];      /* shape[0] is the contiguous dimension */
+    uint64_t offset;        /* relative to the data region */
+    uint64_t nbytes;        /* GGmlTypeSize::elements_to_bytes(shape); 0 if the type's size is unknown */
+    const void *data;       /* NULL when the file does not hold the whole tensor */
+} ggq_gguf_tensor;
+
+typedef struct ggq_gguf_kv {
+    const char *key;        /* not NUL-terminated */
+    size_t key_len;
+    uint32_t type;          /* GGQ_META_* */
+    const void *value;      /* raw value bytes as stored (strings: u64 length + bytes; arrays: type, count, items) */
+    size_t value_len;
+} ggq_gguf_kv;
+
+/* GGuf::new over caller memory (which must outlive the handle). */
+ggq_gguf_error ggq_gguf_parse(const void *data, size_t len, ggq_gguf **out);
+/* Maps the file read-only and parses it. */
+ggq_gguf_error ggq_gguf_open(const char *path, ggq_gguf **out);
+void ggq_gguf_close(ggq_gguf *g);
+/* The offending key / tensor name of the last DUP_KEY / DUP_TENSOR on this thread. */
+const char *ggq_gguf_last_name(void);
+const char *ggq_gguf_error_str(ggq_gguf_error e);
+
+ggq_gguf_error ggq_gguf_get_info(const ggq_gguf *g, ggq_gguf_info *out);
+/* Tensors and key/values keep the file's order (the reference's IndexMap does too). */
+ggq_gguf_error ggq_gguf_tensor_at(const ggq_gguf *g, size_t index, ggq_gguf_tensor *out);
+ggq_gguf_error ggq_gguf_find_tensor(const ggq_gguf *g, const char *name, ggq_gguf_tensor *out);
+ggq_gguf_error ggq_gguf_kv_at(const ggq_gguf *g, size_t index, ggq_gguf_kv *out);
+ggq_gguf_error ggq_gguf_find_kv(const ggq_gguf *g, const char *key, ggq_gguf_kv *out);
+
+/* Bytes per block / elements per block of EVERY GGmlType as stored in GGUF files (also the
+ * types this library cannot decode); 0 for ids that are not in the format. */
+size_t ggq_gguf_type_bytes(uint32_t ggml_type);
+size_t ggq_gguf_type_elems(uint32_t ggml_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGQ_GGUF_H */

@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ggq.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ggq_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for h in ("ggq.h", "ggq_gguf.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ggq_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
