@@ -5,6 +5,7 @@
 #include "../../include/ggq.h"
 #include "kernels.h"
 #include "quantize.h"
+#include "schedule.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -105,31 +106,6 @@ HostGeom host_geom(const TypeInfo *ti, uint32_t out_ty) {
     uint64_t elems = (uint64_t)WG_THREADS * epl * STORES_PER_THREAD;
     return {elems, elems / ti->elems, elems / ti->elems * ti->bytes};
 }
-// Burst prefetch schedule {period, lead} per (block type, output width), in tiles:
-// the best region of a period x lead sweep through the batch kernel on an MI355X
-// (`ubench 1024 5 swb <fmt>`, 1 Gi elements per launch).  f32 output gains 13-30 % over
-// no prefetch (the 8-bit formats 1-2 %).  With 2-byte output the reads are a larger
-// share of the traffic; bunching them gains 2-20 % for the low-bit formats and
-// nothing for 6- and 8-bit ones, where it stays off.
-Prefetch prefetch_for(uint32_t ty, uint32_t out_ty) {
-    if (out_ty != GGQ_TYPE_F32) {
-        switch (ty) {
-        case GGQ_TYPE_Q2K: return {640, 2048};
-        case GGQ_TYPE_Q3K: return {512, 1536};
-        case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: return {768, 1024};
-        case GGQ_TYPE_Q5K: return {640, 1024};
-        case GGQ_TYPE_Q4_0: case GGQ_TYPE_IQ4NL: case GGQ_TYPE_Q4_1:
-        case GGQ_TYPE_Q5_0: case GGQ_TYPE_Q5_1: return {384, 1536};
-        default: return {0, 0};
-        }
-    }
-    switch (ty) {
-    case GGQ_TYPE_Q3K: return {1024, 2048};
-    case GGQ_TYPE_Q6K: return {1024, 1536};
-    case GGQ_TYPE_Q8K: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: return {1024, 1280};
-    default: return {1280, 1536};
-    }
-}
 // gridDim.x limit kept well below 2^31; larger tensors take several launches
 constexpr uint64_t kMaxGrid = 1u << 30;
 
@@ -156,7 +132,7 @@ ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t b
             hipLaunchKernelGGL((deq_one<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
                                (const uint8_t *)d_src + t0 * G::TBYTES,                       \
                                (typename O::T *)d_dst + t0 * G::ELEMS, blocks - t0 * G::TB,   \
-                               prefetch_for(ID, out_id<O>()));                                \
+                               prefetch_for(ID, out_id<O>(), false));                         \
         }                                                                                     \
         break;                                                                                \
     }
@@ -295,7 +271,7 @@ ggq_status launch_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hi
         for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                     \
             uint64_t n = std::min(kMaxGrid, ntiles - t0);                                        \
             hipLaunchKernelGGL((deq_batch<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
-                               d_table + t0, n, prefetch_for(ID, out_id<O>()));                 \
+                               d_table + t0, n, prefetch_for(ID, out_id<O>(), true));           \
         }                                                                                        \
         break;
         GGQ_FORMATS(X)
@@ -759,6 +735,12 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
     const uint8_t *s = (const uint8_t *)h_src;
     uint8_t *d = (uint8_t *)d_dst;
     ggq_status rc = GGQ_OK;
+    bool src_pinned = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, h_src) == hipSuccess) src_pinned = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();      // ordinary pageable memory is "not found", not an error
+    }
     // find the slot that was used least recently: slots alternate, so continue
     // from the first idle one
     int slot = c->busy[0] && !c->busy[1] ? 1 : 0;
@@ -768,9 +750,15 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
             if (!hip_ok(hipEventSynchronize(c->done[slot]), "hipEventSynchronize")) { rc = GGQ_DEVICE; break; }
             c->busy[slot] = false;
         }
-        memcpy(c->h_in[slot], s + done * ti->bytes, nb * ti->bytes);
+        // page-locked sources go to the device straight from where they are; pageable ones
+        // are first copied into the slot's pinned buffer
+        const void *from = s + done * ti->bytes;
+        if (!src_pinned) {
+            memcpy(c->h_in[slot], from, nb * ti->bytes);
+            from = c->h_in[slot];
+        }
         hipStream_t q = c->stream[slot];
-        if (!hip_ok(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], nb * ti->bytes, hipMemcpyHostToDevice, q), "H2D")) {
+        if (!hip_ok(hipMemcpyAsync(c->d_in[slot], from, nb * ti->bytes, hipMemcpyHostToDevice, q), "H2D")) {
             rc = GGQ_DEVICE;
             break;
         }

@@ -20,6 +20,7 @@
 #include "kernels.h"
 #include "kernels_v2.h"
 #include "quantize.h"
+#include "schedule.h"
 
 using namespace ggq;
 
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void k_fill_span(float4v *dst, uint64_t n16) {
     }
 }
 
+enum { Q4K_ID = 12, Q6K_ID = 14, Q2K_ID = 10, Q3K_ID = 11, Q5K_ID = 13, Q8K_ID = 15, IQ4XS_ID = 23, IQ4NL_ID = 20,
+       Q4_0_ID = 2, Q4_1_ID = 3, Q5_0_ID = 6, Q5_1_ID = 7, Q8_0_ID = 8, Q8_1_ID = 9 };
 typedef UbVariant Variant;   // name, algorithmic bytes per launch, launcher, samples
 
 // period x lead sweep of the shipped kernel for one format / output type
@@ -73,8 +76,8 @@ void add_sweep(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in
     const uint64_t blocks = elems / F::N;
     const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
     const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
-    static const uint32_t periods[] = {0, 256, 320, 384, 448, 512, 640, 768, 1024};
-    static const uint32_t leads[] = {768, 1024, 1280, 1536, 2048, 3072};
+    static const uint32_t periods[] = {0, 384, 512, 640, 768, 1024, 1280, 1536};
+    static const uint32_t leads[] = {1024, 1280, 1536, 2048, 3072};
     for (uint32_t P : periods)
         for (uint32_t L : leads) {
             if (P == 0 && L != leads[0]) continue;
@@ -311,7 +314,8 @@ int main(int argc, char **argv) {
         double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));                   \
         vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
                           hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,     \
-                                             (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{512, 1536}); }, {}}); \
+                                             (const uint8_t *)d_in, (typename O::T *)d_out, blocks,         \
+                                             prefetch_for(F##_ID, sizeof(typename O::T) == 4 ? 0u : 1u, false)); }, {}}); \
     }
 #define BURST(PERIOD, K, NEAR, LABEL)                                                                       \
     {                                                                                                       \
@@ -486,6 +490,11 @@ int main(int argc, char **argv) {
     SHIP(Q6K, OutF16, "ship Q6K f16")
     SHIP(Q4K, OutBF16, "ship Q4K bf16")
     SHIP(Q8_0, OutF16, "ship Q8_0 f16")
+    SHIP(Q2K, OutF16, "ship Q2K f16")
+    SHIP(Q3K, OutF16, "ship Q3K f16")
+    SHIP(Q5K, OutF16, "ship Q5K f16")
+    SHIP(Q4_0, OutF16, "ship Q4_0 f16")
+    SHIP(IQ4XS, OutBF16, "ship IQ4XS bf16")
     WGT4(Q4K, OutF32, true, 4096, 512, 0, 1, 0, "s3 T4096 wg512 nt PF0")
     WGT4(Q4K, OutF32, true, 4096, 512, 0, 1, 1024, "s3 T4096 wg512 nt PF1024")
     WGT4(Q4K, OutF32, true, 4096, 512, 0, 1, 2048, "s3 T4096 wg512 nt PF2048")
