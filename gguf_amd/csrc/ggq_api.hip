@@ -3,9 +3,11 @@
 // The C ABI is declared in include/ggq.h, which cites the reference interface
 // each entry point replaces.
 #include "../../include/ggq.h"
+#include "../../include/ggq_gguf.h"
 #include "kernels.h"
 #include "quantize.h"
 #include "schedule.h"
+#include "rearrange.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -609,6 +611,75 @@ ggq_status ggq_quantize_slice(uint32_t ty, uint32_t in_ty, void *dst, size_t dst
     }
     pool_put(c);
     return rc;
+}
+
+// ---- rearrangement -----------------------------------------------------------------
+static ggq_status row_bytes_of(uint32_t ty, uint64_t row_elems, uint64_t *out) {
+    const uint64_t be = ggq_gguf_type_elems(ty), bb = ggq_gguf_type_bytes(ty);
+    if (be == 0) return GGQ_UNSUPPORTED;
+    if (row_elems == 0 || row_elems % be != 0) return GGQ_INDIVISIBLE;
+    *out = row_elems / be * bb;
+    return GGQ_OK;
+}
+
+ggq_status ggq_concat_rows_device(uint32_t ty, uint64_t row_elems, void *d_dst, const void *const *d_parts,
+                                  const uint64_t *part_rows, size_t n_parts, void *hip_stream) {
+    uint64_t rb = 0;
+    ggq_status st = row_bytes_of(ty, row_elems, &rb);
+    if (st != GGQ_OK) return st;
+    if (!d_dst || !d_parts || !part_rows) return GGQ_INVALID;
+    uint8_t *out = (uint8_t *)d_dst;
+    for (size_t i = 0; i < n_parts; ++i) {
+        const uint64_t n = part_rows[i] * rb;
+        if (n == 0) continue;
+        if (!d_parts[i]) return GGQ_INVALID;
+        HIP_TRY(hipMemcpyAsync(out, d_parts[i], n, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+        out += n;
+    }
+    return GGQ_OK;
+}
+
+ggq_status ggq_split_rows_device(uint32_t ty, uint64_t row_elems, const void *d_src, void *const *d_parts,
+                                 const uint64_t *part_rows, size_t n_parts, void *hip_stream) {
+    uint64_t rb = 0;
+    ggq_status st = row_bytes_of(ty, row_elems, &rb);
+    if (st != GGQ_OK) return st;
+    if (!d_src || !d_parts || !part_rows) return GGQ_INVALID;
+    const uint8_t *in = (const uint8_t *)d_src;
+    for (size_t i = 0; i < n_parts; ++i) {
+        const uint64_t n = part_rows[i] * rb;
+        if (n == 0) continue;
+        if (!d_parts[i]) return GGQ_INVALID;
+        HIP_TRY(hipMemcpyAsync(d_parts[i], in, n, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+        in += n;
+    }
+    return GGQ_OK;
+}
+
+ggq_status ggq_permute_qk_device(uint32_t ty, uint64_t row_elems, uint64_t rows, uint64_t n_head, void *d_dst,
+                                 const void *d_src, void *hip_stream) {
+    uint64_t rb = 0;
+    ggq_status st = row_bytes_of(ty, row_elems, &rb);
+    if (st != GGQ_OK) return st;
+    if (n_head == 0 || rows % (2 * n_head) != 0) return GGQ_INDIVISIBLE;
+    if (rows == 0) return GGQ_OK;
+    if (!d_dst || !d_src || d_dst == d_src) return GGQ_INVALID;
+    const uint64_t dh = rows / n_head;
+    const uintptr_t a = (uintptr_t)d_dst | (uintptr_t)d_src | (uintptr_t)rb;
+    const uint32_t vec = a % 16 == 0 ? 16 : a % 4 == 0 ? 4 : a % 2 == 0 ? 2 : 1;
+    const uint64_t pieces = rb / vec * rows;
+    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+    const uint64_t wgs = (pieces + per_wg - 1) / per_wg;
+    if (wgs > kMaxGrid) return GGQ_INVALID;
+    hipStream_t q = (hipStream_t)hip_stream;
+    uint8_t *o = (uint8_t *)d_dst;
+    const uint8_t *i = (const uint8_t *)d_src;
+    if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
+    else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
+    else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows<2>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
+    else hipLaunchKernelGGL((permute_qk_rows<1>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
 }
 
 // ---- batch ------------------------------------------------------------------------

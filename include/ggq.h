@@ -118,6 +118,30 @@ ggq_status ggq_quantize_device(uint32_t ggml_type, uint32_t in_type,
                                const void *d_src, size_t src_elems,
                                void *hip_stream);
 
+/* ---- block-granular rearrangement (no decoding) ------------------------------
+ * Device forms of the reference's merge-linear / split-linear / permute-qk operators
+ * (xtask/src/utils/operator/merge.rs:224-358, permute_qk.rs:46-69).  A tensor of shape
+ * [row_elems, rows] is `rows` rows of elements_to_bytes([row_elems]) bytes each; any
+ * GGmlType with a known block size is accepted (blocks stay opaque), also the ones this
+ * library cannot decode.  row_elems must be a whole number of blocks (GGQ_INDIVISIBLE).
+ * All three enqueue on `hip_stream` and do not synchronize.
+ *
+ * ggq_concat_rows_device : `concat(1, parts)` (merge.rs:279-324) -- merge_qkv,
+ *   merge_gate_up: the parts' rows one after another.  part_rows[i] rows from d_parts[i].
+ * ggq_split_rows_device  : `split(1, tensor, sizes)` (merge.rs:326-358) -- split_qkv,
+ *   split_gate_up: the inverse.
+ * ggq_permute_qk_device  : `permute_qk(tensor, n_head)` (permute_qk.rs:46-69): within every
+ *   head of dh = rows / n_head rows, dst row 2b + a <- src row a * dh/2 + b.
+ *   rows must be a multiple of 2 * n_head (GGQ_INDIVISIBLE otherwise). */
+ggq_status ggq_concat_rows_device(uint32_t ggml_type, uint64_t row_elems, void *d_dst,
+                                  const void *const *d_parts, const uint64_t *part_rows, size_t n_parts,
+                                  void *hip_stream);
+ggq_status ggq_split_rows_device(uint32_t ggml_type, uint64_t row_elems, const void *d_src,
+                                 void *const *d_parts, const uint64_t *part_rows, size_t n_parts,
+                                 void *hip_stream);
+ggq_status ggq_permute_qk_device(uint32_t ggml_type, uint64_t row_elems, uint64_t rows, uint64_t n_head,
+                                 void *d_dst, const void *d_src, void *hip_stream);
+
 /* ---- dequantize, batch of device-resident tensors -------------------------
  * One call decodes many tensors (a whole model's tensor table) with one kernel
  * launch per block type present, instead of one per tensor.  Stands in for the
