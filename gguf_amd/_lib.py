@@ -43,6 +43,9 @@ class ggq_gguf_kv(ctypes.Structure):
                 ("value", ctypes.c_void_p), ("value_len", ctypes.c_size_t)]
 
 
+# DataFuture::get as a C callback: (user, tensor index, nbytes) -> pointer to the bytes
+ggq_gguf_data_fn = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64)
+
 # every symbol include/ggq.h and include/ggq_gguf.h declare: name -> (restype, argtypes)
 _vp, _sz, _u32, _int = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
 SYMBOLS = {
@@ -81,6 +84,18 @@ SYMBOLS = {
     "ggq_gguf_find_kv": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ggq_gguf_kv)]),
     "ggq_gguf_type_bytes": (_sz, [_u32]),
     "ggq_gguf_type_elems": (_sz, [_u32]),
+    "ggq_gguf_writer_create": (_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _int, ctypes.POINTER(_vp)]),
+    "ggq_gguf_writer_alignment": (_int, [_vp, _u32]),
+    "ggq_gguf_writer_kv": (_int, [_vp, ctypes.c_char_p, _sz, _u32, ctypes.c_char_p, _sz]),
+    "ggq_gguf_writer_tensor": (_int, [_vp, ctypes.c_char_p, _sz, _u32, ctypes.POINTER(ctypes.c_uint64), _u32, _vp,
+                                      ggq_gguf_data_fn, _vp]),
+    "ggq_gguf_writer_written_bytes": (ctypes.c_uint64, [_vp]),
+    "ggq_gguf_writer_alignment_value": (ctypes.c_uint64, [_vp]),
+    "ggq_gguf_writer_finish": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "ggq_gguf_writer_destroy": (None, [_vp]),
+    "ggq_gguf_plan_shards": (_int, [_u32, ctypes.POINTER(ggq_gguf_kv), _sz, ctypes.POINTER(ggq_gguf_tensor), _sz,
+                                    ctypes.c_uint64, ctypes.c_uint64, _int, ctypes.POINTER(_u32),
+                                    ctypes.POINTER(_sz)]),
 }
 
 if not os.path.exists(LIB_PATH):

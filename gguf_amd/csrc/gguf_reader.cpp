@@ -321,6 +321,7 @@ const char *ggq_gguf_error_str(ggq_gguf_error e) {
     case GGQ_GGUF_VALUE_TYPE: return "unknown metadata value type";
     case GGQ_GGUF_NOT_FOUND: return "not found";
     case GGQ_GGUF_INVALID: return "invalid argument";
+    case GGQ_GGUF_INDIVISIBLE: return "shape is not a whole number of blocks of the type";
     }
     return "unknown error";
 }

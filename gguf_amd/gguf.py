@@ -16,7 +16,7 @@ from .quants import GGmlType, block_bytes, block_elems
 OK = 0
 ERRORS = {1: "Eos", 2: "Utf8", 3: "Bool", 4: "MagicMismatch", 5: "EndianNotSupport", 6: "VersionNotSupport",
           7: "AlignmentTypeMismatch", 8: "DuplicateMetaKey", 9: "DuplicateTensorName", 10: "Io",
-          11: "ValueType", 12: "NotFound", 13: "Invalid"}
+          11: "ValueType", 12: "NotFound", 13: "Invalid", 14: "Indivisible"}
 DEFAULT_ALIGNMENT = 32
 
 _SCALAR = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 6: "<f", 7: "<?", 10: "<Q", 11: "<q", 12: "<d"}
@@ -227,6 +227,118 @@ def build_gguf(meta, tensors, alignment=None, with_data=True):
             out += b"\0" * (base + off - len(out))
             out += np.ascontiguousarray(data).view(np.uint8).tobytes()
     return bytes(out)
+
+
+class GGufFileWriter:
+    """GGufFileWriter + GGufTensorWriter of the reference (ggus/src/write/file_writer.rs:39-137) in one
+    object: key/values, then tensors, then finish().  path=None gives the byte-counting simulator
+    (GGufFileSimulator / GGufTensorSimulator, simulator.rs:26-95)."""
+
+    def __init__(self, path, n_tensors=0, n_kv=0, write_data=True, alignment=None):
+        h = ctypes.c_void_p()
+        _check(lib.ggq_gguf_writer_create(None if path is None else str(path).encode(), n_tensors, n_kv,
+                                          int(write_data), ctypes.byref(h)))
+        self._h = h
+        self._keep = []          # data buffers and callbacks must outlive finish()
+        self._error = None
+        if alignment is not None:
+            self.write_alignment(alignment)
+
+    @property
+    def alignment(self):
+        return lib.ggq_gguf_writer_alignment_value(self._h)
+
+    def write_alignment(self, alignment):
+        _check(lib.ggq_gguf_writer_alignment(self._h, alignment))
+
+    def write_meta_kv(self, key, ty, value):
+        """value: the raw bytes of the value as stored (what GGufMetaMap::get returns)."""
+        k = key.encode()
+        _check(lib.ggq_gguf_writer_kv(self._h, k, len(k), ty, bytes(value), len(value)))
+
+    def write_meta(self, key, value):
+        ty, b = _enc_value(value)
+        self.write_meta_kv(key, ty, b)
+
+    def write_tensor(self, name, ty, shape, data=None):
+        """data: None, a uint8 array / bytes, or a callable () -> uint8 array evaluated when finish()
+        reaches the tensor (the reference's lazy DataPromise, xtask/src/utils/mod.rs)."""
+        n = name.encode()
+        shp = (ctypes.c_uint64 * len(shape))(*shape)
+        ptr, fn = None, _lib.ggq_gguf_data_fn(0)
+        if callable(data):
+            produce = data
+
+            def get(_user, _index, nbytes, produce=produce):
+                try:
+                    arr = np.ascontiguousarray(produce()).reshape(-1).view(np.uint8)
+                except BaseException as e:   # must not unwind through the C caller
+                    self._error = e
+                    return None
+                if arr.size != nbytes:
+                    return None
+                self._current = arr          # valid until the next call
+                return arr.ctypes.data
+            fn = _lib.ggq_gguf_data_fn(get)
+            self._keep.append(fn)
+        elif data is not None:
+            arr = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray))
+                                       else data).reshape(-1).view(np.uint8)
+            self._keep.append(arr)
+            ptr = arr.ctypes.data
+        _check(lib.ggq_gguf_writer_tensor(self._h, n, len(n), int(ty), shp, len(shape), ptr, fn, None))
+
+    def written_bytes(self):
+        return lib.ggq_gguf_writer_written_bytes(self._h)
+
+    def finish(self):
+        n = ctypes.c_uint64()
+        try:
+            code = lib.ggq_gguf_writer_finish(self._h, ctypes.byref(n))
+            if self._error is not None:
+                raise self._error
+            _check(code)
+        finally:
+            self.close()
+        return n.value
+
+    def close(self):
+        if self._h:
+            lib.ggq_gguf_writer_destroy(self._h)
+            self._h = None
+            self._keep = []
+            self._current = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_shards(alignment, meta_kvs, tensors, max_tensor_count=2 ** 64 - 1, max_file_size=2 ** 64 - 1,
+                no_tensor_first=False):
+    """Shard index per tensor as Content::write_files plans it (xtask/src/utils/write.rs:21-51).
+    meta_kvs: [(key, type id, raw value bytes)]; tensors: [(name, ggml type, shape)]."""
+    keep = []
+    kvs = (_lib.ggq_gguf_kv * max(1, len(meta_kvs)))()
+    for i, (k, ty, v) in enumerate(meta_kvs):
+        kb, vb = ctypes.create_string_buffer(k.encode(), len(k.encode())), ctypes.create_string_buffer(bytes(v), len(v))
+        keep += [kb, vb]
+        kvs[i].key, kvs[i].key_len = ctypes.addressof(kb), len(kb)
+        kvs[i].type, kvs[i].value, kvs[i].value_len = ty, ctypes.addressof(vb), len(vb)
+    ts = (_lib.ggq_gguf_tensor * max(1, len(tensors)))()
+    for i, (name, ty, shape) in enumerate(tensors):
+        nb = ctypes.create_string_buffer(name.encode(), len(name.encode()))
+        keep.append(nb)
+        ts[i].name, ts[i].name_len, ts[i].ggml_type, ts[i].ndim = ctypes.addressof(nb), len(nb), int(ty), len(shape)
+        for j, d in enumerate(shape[:4]):
+            ts[i].shape[j] = d
+    shard_of = (ctypes.c_uint32 * max(1, len(tensors)))()
+    n = ctypes.c_size_t()
+    _check(lib.ggq_gguf_plan_shards(alignment, kvs, len(meta_kvs), ts, len(tensors), max_tensor_count, max_file_size,
+                                    int(no_tensor_first), shard_of, ctypes.byref(n)))
+    return list(shard_of[:len(tensors)]), n.value
 
 
 # ---- whole-file decode ---------------------------------------------------------------------

@@ -43,7 +43,9 @@ typedef enum ggq_gguf_error {
     GGQ_GGUF_IO = 10,              /* open / fstat / mmap failed (ggq_gguf_open only)     */
     GGQ_GGUF_VALUE_TYPE = 11,      /* unknown metadata value type id                      */
     GGQ_GGUF_NOT_FOUND = 12,       /* no such key / tensor / index                        */
-    GGQ_GGUF_INVALID = 13          /* null argument                                       */
+    GGQ_GGUF_INVALID = 13,         /* null argument / call out of order                   */
+    GGQ_GGUF_INDIVISIBLE = 14      /* shape[0] is not a whole number of blocks (the reference asserts,
+                                      ggus/src/tensor.rs:83-96), or the type has no known size */
 } ggq_gguf_error;
 
 /* GGufMetaDataValueType (ggus/src/metadata/mod.rs) */
@@ -104,6 +106,68 @@ ggq_gguf_error ggq_gguf_find_kv(const ggq_gguf *g, const char *key, ggq_gguf_kv 
  * types this library cannot decode); 0 for ids that are not in the format. */
 size_t ggq_gguf_type_bytes(uint32_t ggml_type);
 size_t ggq_gguf_type_elems(uint32_t ggml_type);
+
+/* ---- writer, simulator, shard planner -----------------------------------------------------
+ * Replaces ggus' write side:
+ *   GGufWriter              ggus/src/write/writer.rs:10-106   (header, string, key/value, tensor
+ *                                                              info, padding, data; byte counter)
+ *   GGufFileWriter /
+ *   GGufTensorWriter        ggus/src/write/file_writer.rs:39-137
+ *   GGufFileSimulator /
+ *   GGufTensorSimulator     ggus/src/write/simulator.rs:26-95  (the same calls into a sink that
+ *                                                              only counts; used to plan shards)
+ *   shard planning          xtask/src/utils/write.rs:21-51
+ * One handle covers both phases: key/values first, then tensors, then finish.  A call out of
+ * phase returns GGQ_GGUF_INVALID.  With path == NULL nothing is written and only bytes are
+ * counted (the simulator). */
+typedef struct ggq_gguf_writer ggq_gguf_writer;
+
+/* DataFuture::get (file_writer.rs:26-29).  Called by ggq_gguf_writer_finish, once per tensor that
+ * was written without a data pointer, in writing order; returns `nbytes` bytes that stay valid
+ * until the next call of it or the end of finish.  This is where a caller hands over a tensor
+ * that is decoded on the GPU only when the file reaches it.  NULL aborts with GGQ_GGUF_IO. */
+typedef const void *(*ggq_gguf_data_fn)(void *user, uint64_t tensor_index, uint64_t nbytes);
+
+/* GGufFileWriter::new (file_writer.rs:42-49): creates/truncates `path` and writes the header
+ * (version 3, the two counts as given -- they are not checked against what follows, as in the
+ * reference).  write_data = 0 writes header, key/values and tensor infos only (finish(false),
+ * file_writer.rs:83-91, 104-106). */
+ggq_gguf_error ggq_gguf_writer_create(const char *path, uint64_t n_tensors, uint64_t n_kv, int write_data,
+                                      ggq_gguf_writer **out);
+/* write_alignment (writer.rs:49-56): the general.alignment key/value as u32. */
+ggq_gguf_error ggq_gguf_writer_alignment(ggq_gguf_writer *w, uint32_t alignment);
+/* write_meta_kv (writer.rs:59-77): `value` = the raw value bytes as stored.  The key
+ * general.alignment also sets the alignment and must carry exactly 4 bytes
+ * (GGQ_GGUF_ALIGNMENT_TYPE otherwise; the reference panics). */
+ggq_gguf_error ggq_gguf_writer_kv(ggq_gguf_writer *w, const char *key, size_t key_len, uint32_t type,
+                                  const void *value, size_t value_len);
+/* write_tensor (file_writer.rs:96-108): pads the running data offset, writes the tensor info
+ * and remembers the data.  data == NULL: fn(user, index, nbytes) supplies it during finish
+ * (both NULL is allowed when nothing will be written). */
+ggq_gguf_error ggq_gguf_writer_tensor(ggq_gguf_writer *w, const char *name, size_t name_len, uint32_t ggml_type,
+                                      const uint64_t *shape, uint32_t ndim, const void *data,
+                                      ggq_gguf_data_fn fn, void *user);
+/* GGufTensorSimulator::written_bytes (simulator.rs:87-94): bytes written so far plus, for every
+ * tensor so far, padding to the alignment and its data.  0 for a NULL handle. */
+uint64_t ggq_gguf_writer_written_bytes(const ggq_gguf_writer *w);
+uint64_t ggq_gguf_writer_alignment_value(const ggq_gguf_writer *w);
+/* GGufTensorWriter::finish (file_writer.rs:111-136): padding + data of every tensor, in order;
+ * flushes and closes the file; *n_bytes = file size. */
+ggq_gguf_error ggq_gguf_writer_finish(ggq_gguf_writer *w, uint64_t *n_bytes);
+void ggq_gguf_writer_destroy(ggq_gguf_writer *w);
+
+/* Shard planning of Content::write_files (xtask/src/utils/write.rs:21-51), decisions identical:
+ * tensors go to the current shard while it holds fewer than max_tensor_count tensors and the
+ * simulated file (first shard: header + alignment + all key/values; later shards: header +
+ * alignment only) stays below max_file_size bytes, judged AFTER adding the tensor; otherwise the
+ * tensor opens a new shard.  no_tensor_first keeps the first shard free of tensors.
+ * Only name, type, ndim and shape of `tensors` and key, type, value of `kvs` are read (the structs
+ * the reader fills can be passed as they are).  shard_of[i] = shard index of tensor i;
+ * *n_shards >= 1. */
+ggq_gguf_error ggq_gguf_plan_shards(uint32_t alignment, const ggq_gguf_kv *kvs, size_t n_kv,
+                                    const ggq_gguf_tensor *tensors, size_t n_tensors, uint64_t max_tensor_count,
+                                    uint64_t max_file_size, int no_tensor_first, uint32_t *shard_of,
+                                    size_t *n_shards);
 
 #ifdef __cplusplus
 }
