@@ -2,11 +2,13 @@
 
     read    Content::new / merge_file        xtask/src/utils/read.rs:4-63
     cast    Operator::cast, Content::cast    xtask/src/utils/operator/cast.rs:11-138, 180-216
+    merge   Content::merge_linear            xtask/src/utils/operator/merge.rs:22-268
+    permute Content::permute_qk              xtask/src/utils/operator/permute_qk.rs:12-69
     write   Content::write_files             xtask/src/utils/write.rs:5-100
 
 Input shards are mapped, not read; a tensor that changes type is produced only when the writer of
 its shard reaches it (the reference's lazy DataPromise): packed bytes go to the device, are decoded /
-re-encoded there, and come back through a pinned buffer that the C++ writer hands to write(2).  One
+re-encoded / rearranged there, and come back through a pinned buffer that the C++ writer hands to write(2).  One
 producer thread per shard keeps the GPU one tensor ahead of the file.  Output file names are the
 caller's business (`stem`); the reference's name grammar is not part of this library.
 """
@@ -19,6 +21,7 @@ import numpy as np
 
 from ._lib import lib
 from .gguf import GGuf, GGufError, GGufFileWriter, plan_shards
+from . import rearrange
 from .quants import GGmlType, Indivisible, Unsupported, block_bytes, block_elems, dequantize_slice, quantize_slice
 
 _FLOATS = (GGmlType.F32, GGmlType.F16, GGmlType.BF16)
@@ -100,23 +103,162 @@ def cast_device(row, src, from_ty, to_ty):
     return out
 
 
+# ---- where a tensor's bytes come from: the reference's DataPromise (xtask/src/utils/mod.rs:98-118) as
+# a small expression tree that is evaluated on the device when the writer reaches the tensor ----------
+
+class Borrowed:
+    """Bytes of an input file (a view of the mapping); None when the file holds none."""
+    lazy = False
+
+    def __init__(self, arr, nbytes):
+        self.arr, self.nbytes = arr, nbytes
+
+    def device(self, dev):
+        import torch
+        if self.arr is None:
+            raise ValueError("the input file holds no data for this tensor")
+        return torch.from_numpy(self.arr).to(dev)
+
+
+class Cast:
+    lazy = True
+
+    def __init__(self, src, row, from_ty, to_ty, nbytes):
+        self.src, self.row, self.from_ty, self.to_ty, self.nbytes = src, row, from_ty, to_ty, nbytes
+
+    def device(self, dev):
+        return cast_device(self.row, self.src.device(dev), self.from_ty, self.to_ty)
+
+
+class Concat:
+    """concat(1, parts) (merge.rs:279-324): rows of the parts one after another."""
+    lazy = True
+
+    def __init__(self, ty, row_elems, parts):          # parts: [(node, rows)]
+        self.ty, self.row_elems, self.parts = ty, row_elems, parts
+        self.nbytes = sum(n.nbytes for n, _ in parts)
+
+    def device(self, dev):
+        return rearrange.concat_rows(self.ty, self.row_elems, [(n.device(dev), r) for n, r in self.parts])
+
+
+class Slice:
+    """One output of split(1, tensor, sizes) (merge.rs:326-358): a run of whole rows."""
+    lazy = True
+
+    def __init__(self, src, start, nbytes):
+        self.src, self.start, self.nbytes = src, start, nbytes
+
+    def device(self, dev):
+        return self.src.device(dev)[self.start:self.start + self.nbytes].clone()
+
+
+class PermuteQK:
+    lazy = True
+
+    def __init__(self, src, ty, row_elems, rows, nh):
+        self.src, self.ty, self.row_elems, self.rows, self.nh, self.nbytes = src, ty, row_elems, rows, nh, src.nbytes
+
+    def device(self, dev):
+        return rearrange.permute_qk(self.ty, self.row_elems, self.rows, self.nh, self.src.device(dev))
+
+
+def _slice(src, start, nbytes):
+    if isinstance(src, Borrowed):                        # stays a view of the mapping
+        return Borrowed(None if src.arr is None else src.arr[start:start + nbytes], nbytes)
+    return Slice(src, start, nbytes)
+
+
+def _type_bytes(ty, shape):
+    n = 1
+    for d in shape:
+        n *= d
+    return n // lib.ggq_gguf_type_elems(int(ty)) * lib.ggq_gguf_type_bytes(int(ty))
+
+
 class Tensor:
     """Tensor of Content (xtask/src/utils/mod.rs:92-96): type, shape, and where the bytes come from."""
-    __slots__ = ("name", "ty", "shape", "src_ty", "src")
+    __slots__ = ("ty", "shape", "data")
 
-    def __init__(self, name, ty, shape, src):
-        self.name, self.ty, self.shape, self.src_ty, self.src = name, GGmlType(ty), list(shape), GGmlType(ty), src
-
-    @property
-    def numel(self):
-        n = 1
-        for s in self.shape:
-            n *= s
-        return n
+    def __init__(self, ty, shape, data):
+        self.ty, self.shape, self.data = GGmlType(ty), list(shape), data
 
     @property
     def nbytes(self):
-        return self.numel // lib.ggq_gguf_type_elems(int(self.ty)) * lib.ggq_gguf_type_bytes(int(self.ty))
+        return _type_bytes(self.ty, self.shape)
+
+
+def _distruct(t):
+    """[c, r] with a leading 1 for vectors (merge.rs:271-277)."""
+    if len(t.shape) == 1:
+        return 1, t.shape[0]
+    if len(t.shape) == 2:
+        return t.shape[0], t.shape[1]
+    raise ValueError(f"invalid tensor shape: {t.shape}")
+
+
+def _concat(tensors):
+    """concat(1, tensors), axis 0 for vectors (merge.rs:279-297)."""
+    ty, shape = tensors[0].ty, list(tensors[0].shape)
+    axis = 0 if len(shape) == 1 else 1
+    for t in tensors[1:]:
+        assert t.ty == ty and len(t.shape) == len(shape)
+        for i, d in enumerate(t.shape):
+            if i == axis:
+                shape[i] += d
+            else:
+                assert shape[i] == d
+    if axis == 0:      # vectors: a "row" is one block
+        be = lib.ggq_gguf_type_elems(int(ty))
+        parts = [(t.data, t.shape[0] // be) for t in tensors]
+        row_elems = be
+    else:
+        parts = [(t.data, _type_bytes(ty, t.shape) // _type_bytes(ty, t.shape[:1])) for t in tensors]
+        row_elems = shape[0]
+    return Tensor(ty, shape, Concat(ty, row_elems, parts))
+
+
+def _split(t, sizes):
+    """split(1, tensor, sizes), axis 0 for vectors (merge.rs:326-358)."""
+    axis = 0 if len(t.shape) == 1 else 1
+    assert t.shape[axis] == sum(sizes)
+    out, start = [], 0
+    for d in sizes:
+        shape = list(t.shape)
+        shape[axis] = d
+        n = _type_bytes(t.ty, shape)
+        out.append(Tensor(t.ty, shape, _slice(t.data, start, n)))
+        start += n
+    return out
+
+
+def merge_qkv(q, k, v):
+    qr, kr, vr = _distruct(q)[1], _distruct(k)[1], _distruct(v)[1]
+    assert qr % kr == 0 and qr >= kr and kr == vr          # merge.rs:231-233
+    return _concat([q, k, v])
+
+
+def split_qkv(t, nh, nkvh):
+    r = _distruct(t)[1]
+    dh = r // (nh + 2 * nkvh)                              # merge.rs:255-257
+    return _split(t, [nh * dh, nkvh * dh, nkvh * dh])
+
+
+def permute_qk_tensor(t, nh):
+    """permute_qk (permute_qk.rs:46-69)."""
+    c, r = _distruct(t)
+    return Tensor(t.ty, t.shape, PermuteQK(t.data, t.ty, c, r, nh))
+
+
+_MERGE = re.compile(r"(attn_q|attn_k|attn_v|ffn_gate|ffn_up|ffn_gate_exps|ffn_up_exps)\.(weight|bias)$")
+# as in the reference, ffn_gate_up_exps is merged but never split: its pattern has no such alternative
+_SPLIT = re.compile(r"(attn_qkv|ffn_gate_up)\.(weight|bias)$")
+_QK = re.compile(r"(attn_q|attn_k|attn_qkv)\.(weight|bias)$")
+# group, slot in the group, pieces a complete group has, merged name (merge.rs:171-211, 224-250)
+_GROUPS = {"attn_q": ("attn", 0), "attn_k": ("attn", 1), "attn_v": ("attn", 2), "ffn_gate": ("ffn", 0),
+           "ffn_up": ("ffn", 1), "ffn_gate_exps": ("moe", 0), "ffn_up_exps": ("moe", 1)}
+_GROUP_SIZE = {"attn": 3, "ffn": 2, "moe": 2}
+_GROUP_NAME = {"attn": "attn_qkv", "ffn": "ffn_gate_up", "moe": "ffn_gate_up_exps"}
 
 
 class Content:
@@ -138,7 +280,7 @@ class Content:
             for t in g.tensors:
                 if t.name in self.tensors:
                     raise GGufError(9, t.name)
-                self.tensors[t.name] = Tensor(t.name, t.ty, t.shape, t.bytes() if t.ptr else None)
+                self.tensors[t.name] = Tensor(t.ty, t.shape, Borrowed(t.bytes() if t.ptr else None, t.nbytes))
 
     def close(self):
         self.tensors = {}
@@ -161,17 +303,93 @@ class Content:
         if isinstance(types, str):
             types = parse_cast(types)
         arch = self.general_architecture()
-        for t in self.tensors.values():
-            to = target_type(arch, t.name, t.shape, types)
+        for name, t in self.tensors.items():
+            to = target_type(arch, name, t.shape, types)
             if to is not None and to != t.ty:
                 if to not in _FLOATS and to not in _QUANTIZABLE:
-                    raise Unsupported(f"{t.name}: no encoder for {to.name}")
+                    raise Unsupported(f"{name}: no encoder for {to.name}")
                 if t.ty not in _FLOATS and block_bytes(t.ty) == 0:
-                    raise Unsupported(f"{t.name}: no decoder for {t.ty.name}")
+                    raise Unsupported(f"{name}: no decoder for {t.ty.name}")
                 be = lib.ggq_gguf_type_elems(int(to))
                 if t.shape[0] % be:
-                    raise Indivisible(f"{t.name}: row of {t.shape[0]} is not a multiple of {be}")
+                    raise Indivisible(f"{name}: row of {t.shape[0]} is not a multiple of {be}")
+                t.data = Cast(t.data, t.shape[0], t.ty, to, _type_bytes(to, t.shape))
                 t.ty = to
+
+    def _heads(self):
+        def u(key):
+            if key not in self.meta_kvs:
+                return None
+            ty, raw = self.meta_kvs[key]
+            return int.from_bytes(raw, "little")
+        arch = self.general_architecture()
+        nh = u(f"{arch}.attention.head_count")
+        if nh is None:
+            raise KeyError(f"{arch}.attention.head_count")
+        nkvh = u(f"{arch}.attention.head_count_kv")
+        return nh, nh if nkvh is None else nkvh           # merge.rs:42-47
+
+    def merge_linear(self, merge=True):
+        """Content::merge_linear (merge.rs:22-80): merge=True joins attn_q/k/v into attn_qkv and
+        ffn_gate/up into ffn_gate_up per name prefix (a merged tensor takes the place of the piece
+        that completes it; incomplete groups are appended at the end); merge=False splits them."""
+        old, self.tensors = self.tensors, {}
+        if merge:
+            groups = {}
+            for name, t in old.items():
+                m = _MERGE.search(name)
+                if not m:
+                    self.tensors[name] = t
+                    continue
+                pre, (piece, wb) = name[:m.start()], m.groups()
+                group, slot = _GROUPS[piece]
+                slots = groups.setdefault((pre, group, wb), {})
+                slots[slot] = t
+                if len(slots) == _GROUP_SIZE[group]:
+                    del groups[(pre, group, wb)]
+                    parts = [slots[i] for i in range(_GROUP_SIZE[group])]
+                    if group == "attn":
+                        merged = merge_qkv(*parts)
+                    else:
+                        if group == "ffn":
+                            assert parts[0].shape[1] == parts[1].shape[1]        # merge.rs:241
+                        merged = _concat(parts)
+                    self.tensors[f"{pre}{_GROUP_NAME[group]}.{wb}"] = merged
+            names = {v: k for k, v in _GROUPS.items()}
+            for (pre, group, wb), slots in groups.items():
+                for slot in sorted(slots):
+                    self.tensors[f"{pre}{names[(group, slot)]}.{wb}"] = slots[slot]
+        else:
+            nh, nkvh = self._heads()
+            for name, t in old.items():
+                m = _SPLIT.search(name)
+                if not m:
+                    self.tensors[name] = t
+                    continue
+                pre, (piece, wb) = name[:m.start()], m.groups()
+                if piece == "attn_qkv":
+                    outs = zip(("attn_q", "attn_k", "attn_v"), split_qkv(t, nh, nkvh))
+                else:
+                    r = t.shape[1] // 2                                            # merge.rs:260-263
+                    outs = zip(("ffn_gate", "ffn_up"), _split(t, [r, r]))
+                for piece_name, part in outs:
+                    self.tensors[f"{pre}{piece_name}.{wb}"] = part
+
+    def permute_qk(self):
+        """Content::permute_qk (permute_qk.rs:12-44)."""
+        nh, nkvh = self._heads()
+        for name, t in list(self.tensors.items()):
+            m = _QK.search(name)
+            if not m:
+                continue
+            piece = m.group(1)
+            if piece == "attn_q":
+                self.tensors[name] = permute_qk_tensor(t, nh)
+            elif piece == "attn_k":
+                self.tensors[name] = permute_qk_tensor(t, nkvh)
+            else:
+                q, k, v = split_qkv(t, nh, nkvh)
+                self.tensors[name] = merge_qkv(permute_qk_tensor(q, nh), permute_qk_tensor(k, nkvh), v)
 
     # ---- writing ------------------------------------------------------------------------------
 
@@ -186,7 +404,7 @@ class Content:
                                          max_tensor_count, max_file_size, no_tensor_first)
         shards = [[] for _ in range(n_shards)]
         for name, s in zip(names, shard_of):
-            shards[s].append(self.tensors[name])
+            shards[s].append((name, self.tensors[name]))
         os.makedirs(out_dir, exist_ok=True)
         paths = [os.path.join(out_dir, f"{stem}.gguf" if n_shards == 1 else f"{stem}-{i + 1:05}-of-{n_shards:05}.gguf")
                  for i in range(n_shards)]
@@ -214,14 +432,18 @@ class Content:
         if i == 0:
             for k, ty, raw in kvs:
                 w.write_meta_kv(k, ty, raw)
-        lazy = [t for t in tensors if t.ty != t.src_ty]
+        lazy = [(name, t) for name, t in tensors if t.data.lazy]
         producer = _Producer(lazy, device) if (write_data and lazy) else None
         try:
-            for t in tensors:
-                if t.ty == t.src_ty or not write_data:
-                    w.write_tensor(t.name, t.ty, t.shape, t.src if write_data else None)
+            for name, t in tensors:
+                if not write_data:
+                    w.write_tensor(name, t.ty, t.shape, None)
+                elif not t.data.lazy:
+                    if t.data.arr is None:
+                        raise ValueError(f"{name}: the input file holds no data for this tensor")
+                    w.write_tensor(name, t.ty, t.shape, t.data.arr)
                 else:
-                    w.write_tensor(t.name, t.ty, t.shape, producer.next)
+                    w.write_tensor(name, t.ty, t.shape, producer.next)
             n_bytes = w.finish()
         finally:
             w.close()
@@ -231,7 +453,7 @@ class Content:
 
 
 class _Producer:
-    """Casts a shard's tensors on the GPU in file order, one tensor ahead of the writer, into two
+    """Evaluates a shard's lazy tensors on the GPU in file order, one tensor ahead of the writer, into two
     pinned host buffers that alternate."""
 
     def __init__(self, tensors, device):
@@ -239,7 +461,7 @@ class _Producer:
         self._torch = torch
         self._tensors = tensors
         self._device = device
-        size = max(t.nbytes for t in tensors)
+        size = max(t.nbytes for _, t in tensors)
         self._bufs = [torch.empty(size, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._free = queue.Queue()
         for b in range(2):
@@ -256,14 +478,15 @@ class _Producer:
             with torch.cuda.device(self._device):
                 stream = torch.cuda.Stream()
                 with torch.cuda.stream(stream):
-                    for t in self._tensors:
+                    for name, t in self._tensors:
                         b = self._free.get()
                         if b is None or self._stop:
                             return
-                        if t.src is None:
-                            raise ValueError(f"{t.name}: the input file holds no data for this tensor")
-                        src = torch.from_numpy(t.src).to(f"cuda:{self._device}", non_blocking=False)
-                        out = cast_device(t.shape[0], src, t.src_ty, t.ty)
+                        try:
+                            out = t.data.device(f"cuda:{self._device}")
+                        except ValueError as e:
+                            raise ValueError(f"{name}: {e}") from None
+                        assert out.numel() == t.nbytes, (name, out.numel(), t.nbytes)
                         host = self._bufs[b][:out.numel()]
                         host.copy_(out, non_blocking=True)
                         stream.synchronize()
@@ -288,9 +511,19 @@ class _Producer:
         self._thread.join(timeout=60)
 
 
-def convert(inputs, out_dir, stem, cast=None, **write_args):
-    """`convert <inputs> -x cast:<types>`: read, mark, write.  Returns the FileInfo list."""
+def convert(inputs, out_dir, stem, steps=(), cast=None, **write_args):
+    """`convert <inputs> -x <steps>`: read, apply the steps in order, write.  A step is
+    ("cast", "linear:f32 ..."), ("merge-linear", True|False) or ("permute-qk",), the operator names
+    of the reference's command line.  Returns the FileInfo list."""
+    steps = list(steps) + ([("cast", cast)] if cast else [])
     with Content(inputs) as c:
-        if cast:
-            c.cast(cast)
+        for step in steps:
+            if step[0] == "cast":
+                c.cast(step[1])
+            elif step[0] == "merge-linear":
+                c.merge_linear(step[1])
+            elif step[0] == "permute-qk":
+                c.permute_qk()
+            else:
+                raise Unsupported(f"unknown step {step[0]}")
         return c.write_files(out_dir, stem, **write_args)

@@ -101,7 +101,7 @@ def test_cast_marks_only_changed_tensors(tmp_path):
     p, _ = _model(tmp_path)
     with C.Content([p]) as c:
         c.cast("linear:f32 norm:f32 embd:f16")
-        changed = [n for n, t in c.tensors.items() if t.ty != t.src_ty]
+        changed = [n for n, t in c.tensors.items() if t.data.lazy]
         assert changed == ["blk.0.attn_qkv.weight", "blk.0.ffn_down.weight", "blk.1.attn_qkv.weight",
                            "blk.1.ffn_down.weight"]
         # metadata-only output needs no device
@@ -152,3 +152,103 @@ def test_convert_cast_matches_oracle(tmp_path, linear, spec):
             assert got[name][0] == int(to)
             assert np.array_equal(got[name][1], want), name
     assert n_cast >= 4
+
+
+# ---- merge-linear / split / permute-qk ----------------------------------------------------------
+
+def _attn_model(tmp_path, ty=T.Q8_0, nh=4, nkvh=2, dh=8, c=64, seed=5):
+    tensors = []
+
+    def add(tname, tty, shape):
+        n = int(np.prod(shape))
+        if tty == T.F32:
+            data = np.random.default_rng(seed + len(tensors)).standard_normal(n).astype(np.float32).view(np.uint8)
+        else:
+            data = synth.random_blocks(tty, n // G.lib.ggq_gguf_type_elems(int(tty)), seed + len(tensors))
+        tensors.append((tname, int(tty), shape, data))
+
+    add("token_embd.weight", T.F16, [c, 16])
+    for i in range(2):
+        add(f"blk.{i}.attn_q.weight", ty, [c, nh * dh])
+        add(f"blk.{i}.attn_q.bias", T.F32, [nh * dh])
+        add(f"blk.{i}.attn_k.weight", ty, [c, nkvh * dh])
+        add(f"blk.{i}.attn_k.bias", T.F32, [nkvh * dh])
+        add(f"blk.{i}.attn_norm.weight", T.F32, [c])
+        add(f"blk.{i}.attn_v.weight", ty, [c, nkvh * dh])
+        add(f"blk.{i}.attn_v.bias", T.F32, [nkvh * dh])
+        add(f"blk.{i}.ffn_gate.weight", ty, [c, 96])
+        add(f"blk.{i}.ffn_up.weight", ty, [c, 96])
+    add("blk.9.ffn_up.weight", ty, [c, 32])             # a group that never completes
+    meta = {"general.architecture": "llama", "llama.attention.head_count": nh, "llama.attention.head_count_kv": nkvh}
+    p = tmp_path / "attn.gguf"
+    p.write_bytes(G.build_gguf(meta, tensors))
+    return p, {t[0]: t for t in tensors}
+
+
+def _np_permute(data, rows, nh):
+    rb = data.size // rows
+    return np.ascontiguousarray(data.reshape(nh, 2, rows // nh // 2, rb).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def _read_all(infos):
+    got = {}
+    for path, *_ in infos:
+        with G.GGuf(path) as g:
+            for t in g.tensors:
+                got[t.name] = (t.ty, list(t.shape), t.bytes().copy())
+    return got
+
+
+def test_merge_linear_names_order_and_shapes(tmp_path):
+    p, src = _attn_model(tmp_path)
+    with C.Content([p]) as c:
+        c.merge_linear(True)
+        names = list(c.tensors)
+        # a merged tensor takes the place of the piece that completed it (merge.rs:27-36)
+        assert names[:7] == ["token_embd.weight", "blk.0.attn_norm.weight", "blk.0.attn_qkv.weight",
+                             "blk.0.attn_qkv.bias", "blk.0.ffn_gate_up.weight", "blk.1.attn_norm.weight",
+                             "blk.1.attn_qkv.weight"]
+        assert names[-1] == "blk.9.ffn_up.weight"        # leftovers at the end (merge.rs:38-40)
+        assert c.tensors["blk.0.attn_qkv.weight"].shape == [64, 64]
+        assert c.tensors["blk.0.attn_qkv.bias"].shape == [64]
+        assert c.tensors["blk.0.ffn_gate_up.weight"].shape == [64, 192]
+        c.merge_linear(False)
+        assert set(c.tensors) == set(src)
+        for name, t in c.tensors.items():
+            assert t.shape == src[name][2] and int(t.ty) == src[name][1]
+
+
+@pytest.mark.gpu
+def test_merge_split_permute_on_device(tmp_path):
+    nh, nkvh, dh = 4, 2, 8
+    p, src = _attn_model(tmp_path, nh=nh, nkvh=nkvh, dh=dh)
+    # merge
+    got = _read_all(C.convert([p], tmp_path / "m", "m", steps=[("merge-linear", True)]))
+    for i in range(2):
+        w = np.concatenate([src[f"blk.{i}.attn_{x}.weight"][3] for x in "qkv"])
+        b = np.concatenate([src[f"blk.{i}.attn_{x}.bias"][3] for x in "qkv"])
+        g = np.concatenate([src[f"blk.{i}.ffn_{x}.weight"][3] for x in ("gate", "up")])
+        assert np.array_equal(got[f"blk.{i}.attn_qkv.weight"][2], w)
+        assert np.array_equal(got[f"blk.{i}.attn_qkv.bias"][2], b)
+        assert np.array_equal(got[f"blk.{i}.ffn_gate_up.weight"][2], g)
+    # merge then split gives the input back
+    back = _read_all(C.convert([p], tmp_path / "s", "s", steps=[("merge-linear", True), ("merge-linear", False)]))
+    assert set(back) == set(src)
+    for name, (_, ty, shape, data) in src.items():
+        assert back[name][0] == ty and back[name][1] == shape and np.array_equal(back[name][2], data), name
+    # permute on separate and on merged tensors, followed by a cast
+    perm = _read_all(C.convert([p], tmp_path / "p", "p", steps=[("permute-qk",)]))
+    both = _read_all(C.convert([p], tmp_path / "b", "b", steps=[("merge-linear", True), ("permute-qk",),
+                                                               ("cast", "linear:f32")]))
+    from oracle import oracle as O
+    for i in range(2):
+        q = _np_permute(src[f"blk.{i}.attn_q.weight"][3], nh * dh, nh)
+        k = _np_permute(src[f"blk.{i}.attn_k.weight"][3], nkvh * dh, nkvh)
+        qb = _np_permute(src[f"blk.{i}.attn_q.bias"][3], nh * dh, nh)
+        assert np.array_equal(perm[f"blk.{i}.attn_q.weight"][2], q)
+        assert np.array_equal(perm[f"blk.{i}.attn_k.weight"][2], k)
+        assert np.array_equal(perm[f"blk.{i}.attn_q.bias"][2], qb)
+        assert np.array_equal(perm[f"blk.{i}.attn_v.weight"][2], src[f"blk.{i}.attn_v.weight"][3])
+        qkv = np.concatenate([q, k, src[f"blk.{i}.attn_v.weight"][3]])
+        assert both[f"blk.{i}.attn_qkv.weight"][0] == 0
+        assert np.array_equal(both[f"blk.{i}.attn_qkv.weight"][2], O.dequantize(int(T.Q8_0), qkv).view(np.uint8))
