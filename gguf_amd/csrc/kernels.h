@@ -13,6 +13,9 @@ namespace ggq {
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 
 // ---- output element types ---------------------------------------------------
 struct OutF32 {
@@ -35,8 +38,15 @@ struct OutF16 {
         // producing multiply into the conversion as v_fma_mixlo_f16(x, y, +0), and
         // (-0) + (+0) = +0 loses the sign of a negative zero product.
         asm volatile("" : "+v"(a), "+v"(b));
-        return (uint32_t)__half_as_ushort(__float2half_rn(a)) |
-               ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
+        // one v_cvt_pk_f16_f32 (round to nearest even) for the pair
+        const float2v v = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2v));
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, const float (&a)[8]) {
+        uint4v v = {pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7])};
+        if (NT) __builtin_nontemporal_store(v, (uint4v *)p);
+        else *(uint4v *)p = v;
     }
     template <bool NT>
     static __device__ __forceinline__ void store(T *p, const float (&a)[4], const float (&b)[4]) {
@@ -51,9 +61,14 @@ struct OutBF16 {
     static constexpr uint32_t EPL = 8;
     static __device__ __forceinline__ uint32_t pk(float a, float b) {
         asm volatile("" : "+v"(a), "+v"(b));   // same reason as OutF16::pk
-        __bf16 x = (__bf16)a, y = (__bf16)b;
-        return (uint32_t)__builtin_bit_cast(unsigned short, x) |
-               ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
+        const float2v v = {a, b};              // one v_cvt_pk_bf16_f32
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    }
+    template <bool NT>
+    static __device__ __forceinline__ void store(T *p, const float (&a)[8]) {
+        uint4v v = {pk(a[0], a[1]), pk(a[2], a[3]), pk(a[4], a[5]), pk(a[6], a[7])};
+        if (NT) __builtin_nontemporal_store(v, (uint4v *)p);
+        else *(uint4v *)p = v;
     }
     template <bool NT>
     static __device__ __forceinline__ void store(T *p, const float (&a)[4], const float (&b)[4]) {
@@ -171,15 +186,10 @@ __device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32
         uint32_t bt = el / F::N, e = el % F::N;
         if (bt < nblk) {
             uint32_t b = off0 + bt * F::BYTES;
-            float y0[4];
-            F::dec4(r, b, e, y0);
-            if constexpr (O::EPL == 4) {
-                O::template store<NT>(out + el, y0);
-            } else {
-                float y1[4];
-                F::dec4(r, b, e + 4, y1);
-                O::template store<NT>(out + el, y0, y1);
-            }
+            const Scale sc = F::scale(r, b, e);      // e % EPL == 0: one sub-block, one scale
+            float y[O::EPL];
+            F::template vals<O::EPL / 4>(r, b, e, sc, y);
+            O::template store<NT>(out + el, y);
         }
     }
     // keeps the prefetch load alive; it is waited for only here, after the stores

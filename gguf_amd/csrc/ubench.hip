@@ -52,6 +52,33 @@ __global__ __launch_bounds__(256) void k_copy(float4v *dst, const float4v *src, 
     }
 }
 
+// pure read: sums 16-byte pieces; the store never happens (the sum of finite test data is not NaN-patterned)
+template <bool NT, int S, int WG>
+__global__ __launch_bounds__(WG) void k_read_shot(float4v *sink, const float4v *src, uint64_t n16) {
+    const uint64_t base = (uint64_t)blockIdx.x * (WG * S) + threadIdx.x;
+    float4v v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const uint64_t i = base + (uint64_t)k * WG;
+        v[k] = i < n16 ? (NT ? __builtin_nontemporal_load(src + i) : src[i]) : float4v{0, 0, 0, 0};
+    }
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < S; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    if (__float_as_uint(acc) == 0x7FC12345u) sink[base] = v[0];
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void k_read_loop(float4v *sink, const float4v *src, uint64_t n16) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    float acc = 0;
+    for (; i < n16; i += stride) {
+        float4v v = NT ? __builtin_nontemporal_load(src + i) : src[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (__float_as_uint(acc) == 0x7FC12345u) sink[threadIdx.x] = float4v{acc, 0, 0, 0};
+}
+
 // each workgroup owns a contiguous span (instead of a grid-stride interleave)
 template <bool NT>
 __global__ __launch_bounds__(256) void k_fill_span(float4v *dst, uint64_t n16) {
@@ -147,6 +174,28 @@ int main(int argc, char **argv) {
     const uint64_t n16 = elems / 4;
     auto grid_mem = [&](int per_cu) { return dim3((unsigned)(cus * per_cu)); };
 
+#define RSHOT(NT, S, WG, LABEL)                                                                             \
+    vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                            \
+                      hipLaunchKernelGGL((k_read_shot<NT, S, WG>), dim3((unsigned)((n16 + WG * S - 1) / (WG * S))), \
+                                         dim3(WG), 0, s, (float4v *)d_in, (const float4v *)d_out, n16); }, {}});
+    RSHOT(false, 1, 256, "read shot plain S1 wg256")
+    RSHOT(false, 2, 256, "read shot plain S2 wg256")
+    RSHOT(false, 4, 256, "read shot plain S4 wg256")
+    RSHOT(false, 2, 512, "read shot plain S2 wg512")
+    RSHOT(false, 4, 512, "read shot plain S4 wg512")
+    RSHOT(false, 8, 512, "read shot plain S8 wg512")
+    RSHOT(true, 2, 512, "read shot nt S2 wg512")
+    RSHOT(true, 4, 512, "read shot nt S4 wg512")
+    RSHOT(true, 1, 512, "read shot nt S1 wg512")
+    RSHOT(false, 1, 512, "read shot plain S1 wg512")
+    vs.push_back({"read loop plain 8/CU", (double)elems * 4, [=](hipStream_t s) {
+                      hipLaunchKernelGGL(k_read_loop<false>, grid_mem(8), dim3(256), 0, s, (float4v *)d_in, (const float4v *)d_out, n16); }, {}});
+    vs.push_back({"read loop nt 8/CU", (double)elems * 4, [=](hipStream_t s) {
+                      hipLaunchKernelGGL(k_read_loop<true>, grid_mem(8), dim3(256), 0, s, (float4v *)d_in, (const float4v *)d_out, n16); }, {}});
+    vs.push_back({"read loop nt 16/CU", (double)elems * 4, [=](hipStream_t s) {
+                      hipLaunchKernelGGL(k_read_loop<true>, grid_mem(16), dim3(256), 0, s, (float4v *)d_in, (const float4v *)d_out, n16); }, {}});
+    vs.push_back({"read loop plain 32/CU", (double)elems * 4, [=](hipStream_t s) {
+                      hipLaunchKernelGGL(k_read_loop<false>, grid_mem(32), dim3(256), 0, s, (float4v *)d_in, (const float4v *)d_out, n16); }, {}});
     vs.push_back({"fill nt grid-stride 8/CU", (double)elems * 4, [=](hipStream_t s) {
                       hipLaunchKernelGGL(k_fill<true>, grid_mem(8), dim3(256), 0, s, (float4v *)d_out, n16); }, {}});
     vs.push_back({"fill plain grid-stride 8/CU", (double)elems * 4, [=](hipStream_t s) {
@@ -463,6 +512,33 @@ int main(int argc, char **argv) {
                           hipLaunchKernelGGL((quant_one<Q, In>), dim3(grid), dim3(WG_THREADS), 0, s,        \
                                              (const typename In::T *)d_out, (uint8_t *)d_in, blocks); }, {}}); \
     }
+#define QNTL(Q, In, L, NTL, NTS, LABEL)                                                                     \
+    {                                                                                                       \
+        typedef QuantGeom<Q, In, L> G;                                                                      \
+        uint64_t blocks = elems / Q::N;                                                                     \
+        unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
+        double bytes = (double)elems * ((double)Q::BYTES / Q::N + sizeof(typename In::T));                  \
+        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
+                          hipLaunchKernelGGL((quant_one<Q, In, L, NTL, NTS>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                             (const typename In::T *)d_out, (uint8_t *)d_in, blocks); }, {}}); \
+    }
+    QNTL(EncQ4_0, InF32, 1, false, false, "qv L1 pl pl Q4_0 from f32")
+    QNTL(EncQ4_0, InF32, 1, true, false, "qv L1 nt pl Q4_0 from f32")
+    QNTL(EncQ4_0, InF32, 1, true, true, "qv L1 nt nt Q4_0 from f32")
+    QNTL(EncQ4_0, InF32, 2, true, false, "qv L2 nt pl Q4_0 from f32")
+    QNTL(EncQ4_0, InF32, 2, true, true, "qv L2 nt nt Q4_0 from f32")
+    QNTL(EncQ8_0, InF32, 1, true, false, "qv L1 nt pl Q8_0 from f32")
+    QNTL(EncQ8_0, InF32, 1, true, true, "qv L1 nt nt Q8_0 from f32")
+    QNTL(EncQ8_0, InF32, 2, true, false, "qv L2 nt pl Q8_0 from f32")
+    QNTL(EncQ8_0, InF32, 2, true, true, "qv L2 nt nt Q8_0 from f32")
+    QNTL(EncQ4_1, InF32, 1, true, false, "qv L1 nt pl Q4_1 from f32")
+    QNTL(EncQ4_1, InF32, 2, true, false, "qv L2 nt pl Q4_1 from f32")
+    QNTL(EncQ5_1, InF32, 1, true, false, "qv L1 nt pl Q5_1 from f32")
+    QNTL(EncQ8K, InF32, 1, true, false, "qv L1 nt pl Q8K from f32")
+    QNTL(EncQ8K, InF32, 2, true, false, "qv L2 nt pl Q8K from f32")
+    QNTL(EncQ8_0, InF16, 1, true, false, "qv L1 nt pl Q8_0 from f16")
+    QNTL(EncQ8_0, InF16, 2, true, false, "qv L2 nt pl Q8_0 from f16")
+    QNTL(EncQ4_0, InBF16, 1, true, false, "qv L1 nt pl Q4_0 from bf16")
     QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
     QNT(EncQ4_1, InF32, "quant Q4_1 from f32")
     QNT(EncQ5_0, InF32, "quant Q5_0 from f32")
