@@ -394,9 +394,11 @@ class Content:
     # ---- writing ------------------------------------------------------------------------------
 
     def write_files(self, out_dir, stem, max_tensor_count=2 ** 63, max_file_size=2 ** 63, no_tensor_first=False,
-                    write_data=True, device=0):
+                    write_data=True, device=0, rank=0, world=1):
         """Content::write_files (write.rs:5-100): plan shards, then one writer thread per shard.
-        Returns [(path, n_tensors, n_meta_kvs, n_bytes)] (FileInfo)."""
+        Returns [(path, n_tensors, n_meta_kvs, n_bytes)] (FileInfo).
+        With world > 1 (one process per GPU) every rank plans the same shards and writes those with
+        index % world == rank on its own device; no data moves between ranks."""
         names = list(self.tensors)
         kvs = [(k, ty, raw) for k, (ty, raw) in self.meta_kvs.items()]
         shard_of, n_shards = plan_shards(self.alignment, kvs, [(n, self.tensors[n].ty, self.tensors[n].shape)
@@ -416,14 +418,14 @@ class Content:
             except BaseException as e:      # reported by the caller's thread
                 errors.append(e)
 
-        threads = [threading.Thread(target=run, args=(i,)) for i in range(n_shards)]
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(n_shards) if i % world == rank]
         for th in threads:
             th.start()
         for th in threads:
             th.join()
         if errors:
             raise errors[0]
-        return results
+        return [r for r in results if r is not None]
 
     def _write_shard(self, i, path, tensors, kvs, write_data, device):
         n_kv = (len(kvs) if i == 0 else 0) + 1

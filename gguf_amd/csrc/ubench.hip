@@ -96,6 +96,7 @@ enum { Q4K_ID = 12, Q6K_ID = 14, Q2K_ID = 10, Q3K_ID = 11, Q5K_ID = 13, Q8K_ID =
        Q4_0_ID = 2, Q4_1_ID = 3, Q5_0_ID = 6, Q5_1_ID = 7, Q8_0_ID = 8, Q8_1_ID = 9 };
 typedef UbVariant Variant;   // name, algorithmic bytes per launch, launcher, samples
 
+static const char *g_sweep_tag = "sw";   // labels start with the mode name so the name filter keeps them
 // period x lead sweep of the shipped kernel for one format / output type
 template <class F, class O>
 void add_sweep(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in, void *d_out, uint64_t elems) {
@@ -103,14 +104,14 @@ void add_sweep(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in
     const uint64_t blocks = elems / F::N;
     const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
     const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
-    static const uint32_t periods[] = {0, 384, 512, 640, 768, 1024, 1280, 1536};
-    static const uint32_t leads[] = {1024, 1280, 1536, 2048, 3072};
+    static const uint32_t periods[] = {0, 256, 384, 512, 640, 768, 1024, 1280, 1536};
+    static const uint32_t leads[] = {512, 768, 1024, 1280, 1536, 2048, 3072};
     for (uint32_t P : periods)
         for (uint32_t L : leads) {
             if (P == 0 && L != leads[0]) continue;
             if (P && L < P) continue;
             char label[96];
-            std::snprintf(label, sizeof label, "sw %s P%u L%u", name, P, P ? L : 0);
+            std::snprintf(label, sizeof label, "%s %s P%u L%u", g_sweep_tag, name, P, P ? L : 0);
             vs.push_back({label, bytes, [=](hipStream_t s) {
                               hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in,
                                                  (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}});
@@ -140,7 +141,7 @@ void add_sweep_batch(std::vector<UbVariant> &vs, const char *name, const uint8_t
             if (P == 0 && L != leads[0]) continue;
             if (P > 1 && L < P) continue;
             char label[96];
-            std::snprintf(label, sizeof label, "swb %s P%u L%u", name, P, P ? L : 0);
+            std::snprintf(label, sizeof label, "%s %s P%u L%u", g_sweep_tag[2] ? g_sweep_tag : "swb", name, P, P ? L : 0);
             vs.push_back({label, bytes, [=](hipStream_t s) {
                               hipLaunchKernelGGL((deq_batch<F, O, true>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s,
                                                  d_tab, ntiles, Prefetch{P, L}); }, {}});
@@ -674,6 +675,20 @@ int main(int argc, char **argv) {
         add_sweep<Q8_0, OutF16>(vs, "Q8_0 f16", d_in, d_out, elems);
         add_sweep<Q4_0, OutF16>(vs, "Q4_0 f16", d_in, d_out, elems);
         add_sweep<Q2K, OutF16>(vs, "Q2K f16", d_in, d_out, elems);
+    }
+    if (argc > 3 && std::strcmp(argv[3], "sw16") == 0) {   // single-tensor kernel, every format, f16 output
+        vs.clear();
+        g_sweep_tag = "sw16";
+#define SW16(F) add_sweep<F, OutF16>(vs, #F " f16", d_in, d_out, elems);
+        SW16(Q4K) SW16(Q6K) SW16(Q2K) SW16(Q3K) SW16(Q5K) SW16(Q8K) SW16(IQ4XS) SW16(IQ4NL) SW16(Q4_0) SW16(Q4_1)
+        SW16(Q5_0) SW16(Q5_1) SW16(Q8_0) SW16(Q8_1)
+    }
+    if (argc > 3 && std::strcmp(argv[3], "swb16") == 0) {  // batch kernel, every format, f16 output
+        vs.clear();
+        g_sweep_tag = "swb16";
+#define SWB16(F) add_sweep_batch<F, OutF16>(vs, #F " f16", d_in, d_out, elems);
+        SWB16(Q4K) SWB16(Q6K) SWB16(Q2K) SWB16(Q3K) SWB16(Q5K) SWB16(Q8K) SWB16(IQ4XS) SWB16(IQ4NL) SWB16(Q4_0) SWB16(Q4_1)
+        SWB16(Q5_0) SWB16(Q5_1) SWB16(Q8_0) SWB16(Q8_1)
     }
     if (argc > 4 && std::strncmp(argv[3], "swb", 3) == 0) {
         vs.clear();

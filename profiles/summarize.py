@@ -31,10 +31,19 @@ def main():
     tag, kt, fetch, write, key = sys.argv[1:6]
     rows = []
     path = find(kt, "kernel_stats.csv")
-    for r in csv.DictReader(open(path)):
-        if "ggq::" in r["Name"]:
-            rows.append({"kernel": short(r["Name"]), "calls": r["Calls"], "avg_ns": r["AverageNs"],
-                         "min_ns": r["MinNs"], "max_ns": r["MaxNs"], "total_ns": r["TotalDurationNs"]})
+    if path:
+        for r in csv.DictReader(open(path)):
+            if "ggq::" in r["Name"]:
+                rows.append({"kernel": short(r["Name"]), "calls": r["Calls"], "avg_ns": r["AverageNs"],
+                             "min_ns": r["MinNs"], "max_ns": r["MaxNs"], "total_ns": r["TotalDurationNs"]})
+    else:   # rocprofv3's default output: one rocpd SQLite database
+        import sqlite3
+        db = sqlite3.connect(find(kt, "_results.db"))
+        for name, n, avg, lo, hi, tot in db.execute(
+                "select name, count(*), avg(duration), min(duration), max(duration), sum(duration) "
+                "from kernels where name like '%ggq::%' group by name order by sum(duration) desc"):
+            rows.append({"kernel": short(name), "calls": n, "avg_ns": round(avg), "min_ns": lo, "max_ns": hi,
+                         "total_ns": tot})
     with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0]))
         w.writeheader()
@@ -42,9 +51,17 @@ def main():
 
     def counter(d, cname):
         agg = {}
-        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
-            if r["Counter_Name"] == cname and "ggq::" in r["Kernel_Name"]:
-                agg.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        path = find(d, "counter_collection.csv")
+        if path:
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == cname and "ggq::" in r["Kernel_Name"]:
+                    agg.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        else:
+            import sqlite3
+            db = sqlite3.connect(find(d, "_results.db"))
+            for name, value in db.execute("select kernel_name, value from counters_collection "
+                                          "where counter_name = ? and kernel_name like '%ggq::%'", (cname,)):
+                agg.setdefault(short(name), []).append(float(value))
         return {k: sum(v) / len(v) for k, v in agg.items()}
 
     fe, wr = counter(fetch, "FETCH_SIZE"), counter(write, "WRITE_SIZE")

@@ -87,6 +87,17 @@ def test_copy_without_cast_and_sharding(tmp_path):
         assert c.alignment == 32
 
 
+def test_ranks_split_the_shards(tmp_path):
+    p, tensors = _model(tmp_path)
+    with C.Content([p]) as c:
+        a = c.write_files(tmp_path / "r", "m", max_tensor_count=3, rank=0, world=2)
+        b = c.write_files(tmp_path / "r", "m", max_tensor_count=3, rank=1, world=2)
+    assert [i[0][-19:] for i in a] == ["00001-of-00003.gguf", "00003-of-00003.gguf"]
+    assert [i[0][-19:] for i in b] == ["00002-of-00003.gguf"]
+    with C.Content([i[0] for i in a + b]) as c:          # any order: the union is the model
+        assert sorted(c.tensors) == sorted(t[0] for t in tensors)
+
+
 def test_merge_rejects_duplicates_and_takes_max_alignment(tmp_path):
     a, _ = _model(tmp_path, "a.gguf", alignment=64)
     b, _ = _model(tmp_path, "b.gguf")
