@@ -216,6 +216,8 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one(const uint8_t *__restrict_
 }
 
 // ---- many tensors per launch: workgroup b decodes tile table[b] -------------------
+// (Touching the table record of a workgroup 64-2048 tiles ahead, to spare that workgroup the
+// miss on its record, was measured 1-2 % slower: the record load is not what the kernel waits for.)
 template <class F, class O, bool NT>
 __global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restrict__ table,
                                                         uint64_t ntiles, Prefetch pf) {
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(WG_THREADS) void widen_vec(const uint2v *__restrict
             O::template store<NT>(dst + 4 * i, y);
         } else {
             uint2v o = {O::pk(y[0], y[1]), O::pk(y[2], y[3])};
-            *(uint2v *)(dst + 4 * i) = o;
+            if (NT) __builtin_nontemporal_store(o, (uint2v *)(dst + 4 * i));
+            else *(uint2v *)(dst + 4 * i) = o;
         }
     }
 }

@@ -416,13 +416,13 @@ __global__ __launch_bounds__(WG_THREADS) void narrow_vec(const typename In::T *_
         uint64_t el = base + (uint64_t)i * WG_THREADS * In::EPL;
         if (el + In::EPL > n) continue;
         float x[In::EPL];
-        In::load(src + el, x);
+        In::template load<true>(src + el, x);
         if constexpr (In::EPL == 4) {
             uint2v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3])};
-            *(uint2v *)(dst + el) = o;
+            __builtin_nontemporal_store(o, (uint2v *)(dst + el));
         } else {
             uint4v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3]), O::pk(x[4], x[5]), O::pk(x[6], x[7])};
-            *(uint4v *)(dst + el) = o;
+            __builtin_nontemporal_store(o, (uint4v *)(dst + el));
         }
     }
 }

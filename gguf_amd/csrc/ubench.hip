@@ -540,6 +540,24 @@ int main(int argc, char **argv) {
     QNTL(EncQ8_0, InF16, 1, true, false, "qv L1 nt pl Q8_0 from f16")
     QNTL(EncQ8_0, InF16, 2, true, false, "qv L2 nt pl Q8_0 from f16")
     QNTL(EncQ4_0, InBF16, 1, true, false, "qv L1 nt pl Q4_0 from bf16")
+    {   // the 1-element "blocks": f16 / bf16 widening and narrowing
+        const uint64_t n4 = elems / 4, per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+        const unsigned grid = (unsigned)((n4 + per_wg - 1) / per_wg);
+        vs.push_back({"widen f16 -> f32", (double)elems * 6, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((widen_vec<false, OutF32, true>), dim3(grid), dim3(WG_THREADS), 0, s,
+                                             (const uint2v *)d_in, (float *)d_out, n4); }, {}});
+        vs.push_back({"widen bf16 -> f32", (double)elems * 6, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((widen_vec<true, OutF32, true>), dim3(grid), dim3(WG_THREADS), 0, s,
+                                             (const uint2v *)d_in, (float *)d_out, n4); }, {}});
+        const uint64_t per_wg_n = (uint64_t)WG_THREADS * STORES_PER_THREAD * InF32::EPL;
+        const unsigned gridn = (unsigned)((elems + per_wg_n - 1) / per_wg_n);
+        vs.push_back({"narrow f32 -> f16", (double)elems * 6, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((narrow_vec<InF32, OutF16>), dim3(gridn), dim3(WG_THREADS), 0, s,
+                                             (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+        vs.push_back({"narrow f32 -> bf16", (double)elems * 6, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((narrow_vec<InF32, OutBF16>), dim3(gridn), dim3(WG_THREADS), 0, s,
+                                             (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+    }
     QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
     QNT(EncQ4_1, InF32, "quant Q4_1 from f32")
     QNT(EncQ5_0, InF32, "quant Q5_0 from f32")
