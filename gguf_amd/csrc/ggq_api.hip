@@ -12,8 +12,13 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -325,6 +330,111 @@ struct ggq_ctx {
 
 namespace {
 
+// Copies between pageable host memory and the pinned staging buffers run on a few helper
+// threads: one thread moves ~10-25 GB/s, PCIe Gen5 moves ~55 GB/s each way, and without help
+// the calling thread's memcpy is what bounds the host entry points.  GGQ_COPY_THREADS sets the
+// number of helpers (default 3; 0 = the caller copies alone).  The helpers are created on first
+// use and never joined (the pool outlives every caller).
+class CopyPool {
+    struct Task {
+        uint8_t *d;
+        const uint8_t *s;
+        size_t n;
+        std::atomic<int> *left;
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Task> q;
+    int helpers = 0;
+    bool started = false;
+
+    void work() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !q.empty(); });
+                t = q.front();
+                q.pop_front();
+            }
+            memcpy(t.d, t.s, t.n);
+            t.left->fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void start() {
+        std::lock_guard<std::mutex> lk(m);
+        if (started) return;
+        started = true;
+        const char *e = std::getenv("GGQ_COPY_THREADS");
+        int n = e ? std::atoi(e) : 3;
+        n = std::max(0, std::min(n, 15));
+        for (int i = 0; i < n; ++i) {
+            try {
+                std::thread([this] { work(); }).detach();
+                ++helpers;
+            } catch (...) {
+                break;
+            }
+        }
+    }
+
+public:
+    void copy(void *dst, const void *src, size_t n) {
+        constexpr size_t kMinSlice = 1u << 20;
+        if (!started) start();
+        const size_t parts = std::min<size_t>((size_t)helpers + 1, n / kMinSlice);
+        if (parts <= 1) {
+            memcpy(dst, src, n);
+            return;
+        }
+        const size_t slice = ((n / parts) + 4095) & ~(size_t)4095;
+        std::atomic<int> left{0};
+        uint8_t *d = (uint8_t *)dst;
+        const uint8_t *s = (const uint8_t *)src;
+        size_t off = slice;   // the caller keeps the first slice
+        {
+            std::lock_guard<std::mutex> lk(m);
+            while (off < n) {
+                const size_t len = std::min(slice, n - off);
+                left.fetch_add(1, std::memory_order_relaxed);
+                q.push_back({d + off, s + off, len, &left});
+                off += len;
+            }
+        }
+        cv.notify_all();
+        memcpy(d, s, std::min(slice, n));
+        // The caller takes queued slices too (its own or another caller's), so a copy finishes
+        // even if no helper is alive, e.g. in a child process after fork.
+        while (left.load(std::memory_order_acquire) != 0) {
+            Task t;
+            bool have = false;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!q.empty()) {
+                    t = q.front();
+                    q.pop_front();
+                    have = true;
+                }
+            }
+            if (have) {
+                memcpy(t.d, t.s, t.n);
+                t.left->fetch_sub(1, std::memory_order_release);
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    }
+};
+
+CopyPool &copy_pool() {
+    static CopyPool *p = new CopyPool();   // leaked on purpose: helpers may outlive static destructors
+    return *p;
+}
+
+}  // namespace
+
+namespace {
+
 void ctx_free(ggq_ctx *c) {
     if (!c) return;
     for (int s = 0; s < ggq_ctx::SLOTS; ++s) {
@@ -508,14 +618,14 @@ ggq_status ggq_dequantize_slice(uint32_t ty, uint32_t out_ty, void *dst, size_t 
         if (!c->busy[k]) return true;
         c->busy[k] = false;
         if (!hip_ok(hipEventSynchronize(c->done[k]), "hipEventSynchronize")) return false;
-        memcpy(d + pend[k].out_off, c->h_out[k], pend[k].out_len);
+        copy_pool().copy(d + pend[k].out_off, c->h_out[k], pend[k].out_len);
         return true;
     };
     while (done_blocks < src_blocks && rc == GGQ_OK) {
         size_t nb = std::min(chunk_blocks, src_blocks - done_blocks);
         size_t in_len = nb * ti->bytes, out_len = nb * ti->elems * ob;
         if (!drain(slot)) { rc = GGQ_DEVICE; break; }
-        memcpy(c->h_in[slot], s + done_blocks * ti->bytes, in_len);
+        copy_pool().copy(c->h_in[slot], s + done_blocks * ti->bytes, in_len);
         hipStream_t q = c->stream[slot];
         bool ok = hip_ok(hipMemcpyAsync(c->d_in[slot], c->h_in[slot], in_len, hipMemcpyHostToDevice, q), "H2D");
         if (ok) {
@@ -582,14 +692,14 @@ ggq_status ggq_quantize_slice(uint32_t ty, uint32_t in_ty, void *dst, size_t dst
         if (!c->busy[k]) return true;
         c->busy[k] = false;
         if (!hip_ok(hipEventSynchronize(c->done[k]), "hipEventSynchronize")) return false;
-        memcpy(d + pend[k].out_off, c->h_in[k], pend[k].out_len);
+        copy_pool().copy(d + pend[k].out_off, c->h_in[k], pend[k].out_len);
         return true;
     };
     while (done_blocks < dst_blocks && rc == GGQ_OK) {
         size_t nb = std::min(chunk_blocks, dst_blocks - done_blocks);
         size_t in_len = nb * ti->elems * ib, out_len = nb * ti->bytes;
         if (!drain(slot)) { rc = GGQ_DEVICE; break; }
-        memcpy(c->h_out[slot], s + done_blocks * ti->elems * ib, in_len);
+        copy_pool().copy(c->h_out[slot], s + done_blocks * ti->elems * ib, in_len);
         hipStream_t q = c->stream[slot];
         bool ok = hip_ok(hipMemcpyAsync(c->d_out[slot], c->h_out[slot], in_len, hipMemcpyHostToDevice, q), "H2D");
         if (ok) {
@@ -825,7 +935,7 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
         // are first copied into the slot's pinned buffer
         const void *from = s + done * ti->bytes;
         if (!src_pinned) {
-            memcpy(c->h_in[slot], from, nb * ti->bytes);
+            copy_pool().copy(c->h_in[slot], from, nb * ti->bytes);
             from = c->h_in[slot];
         }
         hipStream_t q = c->stream[slot];
