@@ -25,3 +25,13 @@ def test_full_program_on_gpu():
     r = _run()
     assert r.returncode == 0, r.stdout + r.stderr
     assert "slice api ok (with device)" in r.stdout
+
+
+def test_ggus_mirror_program():
+    """gguf_amd/host/ggus.hpp: the reference's container tests (simulator.rs:110-131,
+    file_writer.rs:150-371, file.rs:313-443) in C++; host only."""
+    exe = os.path.join(ROOT, "gguf_amd", "host", "test_ggus_api")
+    assert os.path.exists(exe), "build it: make -C gguf_amd/host"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ggus api ok" in r.stdout
