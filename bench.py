@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="llama7b_q4_k_m")
     ap.add_argument("--out", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank's share is one whole workload (default); strong: ONE workload "
+                         "split over the ranks (for sets that do not fit one GPU, e.g. llama70b_q4_k_m_iq4nl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -138,13 +141,19 @@ def main():
 
     # ---- the job: `world` tensor sets, dealt to ranks by the index partition -------
     base = synth.workload(args.workload)
-    items = [(f"set{r}.{n}", ty, ne) for r in range(world) for (n, ty, ne) in base]
+    sets = world if args.scaling == "weak" else 1
+    items = [(f"set{r}.{n}", ty, ne) for r in range(sets) for (n, ty, ne) in base]
     mine = shard.partition(items, world)[rank]
     out_dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.out]
     ob = 4 if args.out == "f32" else 2
     out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[args.out]
 
     my_elems = sum(p.elems for p in mine)
+    need = my_elems * ob + sum(p.blocks * block_bytes(p.ggml_type) for p in mine)
+    free = torch.cuda.mem_get_info(dev)[0]
+    if need > 0.97 * free:
+        sys.exit(f"rank {rank}: this share needs {need / 2**30:.1f} GiB of HBM, {free / 2**30:.1f} GiB are free; "
+                 f"use more GPUs with --scaling strong, or --out f16")
     dst_all = torch.empty(my_elems, dtype=out_dt, device=dev)
     by_type = {}
     at = 0
@@ -213,9 +222,9 @@ def main():
         rec = {
             "metric": "dequantized_GBps", "value": round(pout / (elapsed / args.steps) / 1e9, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "io": "u8->" + args.out, "data": "synthetic",
-            "config": {"workload": (args.workload if world == 1 else f"{world} x {args.workload}")
+            "config": {"workload": (args.workload if sets == 1 else f"{sets} x {args.workload}")
                        + (f" (REHEARSAL: {world} ranks share {ndev} GPU)" if shared else ""),
                        "tensors": len(items), "elements": total_elems, "packed_bytes": pin,
                        "decoded_bytes": pout, "partition": "index (LPT), no collective",
