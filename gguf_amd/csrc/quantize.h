@@ -65,14 +65,26 @@ struct InBF16 {
 
 // ---- scalar helpers with the reference's semantics -------------------------------
 __device__ __forceinline__ bool is_nan(float x) { return x != x; }
-// Rust `as u8` / `as i8` on f32: saturating, NaN -> 0
-// (fmaxf / fminf return the other operand when one is NaN, so the clamps are branch-free)
-__device__ __forceinline__ uint32_t sat_u8(float x) {
-    return (uint32_t)(int)fminf(fmaxf(x, 0.0f), 255.0f);          // negatives, zeros and NaN -> 0
+// Rust `as u8` / `as i8` on f32: saturating, NaN -> 0.  The hardware conversions behave exactly
+// so (out-of-range saturates, NaN gives 0); they are issued as asm because the same conversion
+// written in C is undefined for those inputs.
+__device__ __forceinline__ int cvt_i32_sat(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
-__device__ __forceinline__ int sat_i8(float x) {
-    x = is_nan(x) ? 0.0f : x;
-    return (int)fminf(fmaxf(x, -128.0f), 127.0f);
+__device__ __forceinline__ uint32_t cvt_u32_sat(float x) {
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t sat_u8(float x) { return min(cvt_u32_sat(x), 255u); }
+__device__ __forceinline__ int sat_i8(float x) { return max(-128, min(cvt_i32_sat(x), 127)); }
+// f32::round (half away from zero) as trunc(x + copysign(pred(0.5), x)): equal to it for every
+// float (checked exhaustively for |x| < 512 on the host; beyond that both sides are far outside
+// the i8 range that follows).  A NaN stays a NaN.
+__device__ __forceinline__ float round_away(float x) {
+    return truncf(__fadd_rn(x, copysignf(0.49999997f, x)));
 }
 // f32::min(x, c) for a non-NaN constant c: a NaN x gives c
 __device__ __forceinline__ float min_c(float x, float c) { return x < c ? x : c; }
@@ -81,6 +93,34 @@ __device__ __forceinline__ uint32_t f2h_bits(float x) {
     return (uint32_t)__half_as_ushort(__float2half_rn(x));
 }
 // ---- reductions over the G lanes of a block (G a power of two, lanes consecutive) --
+// All of them are butterflies in which, before the step at distance M, the 2^k lanes of each
+// half already agree; the step only needs ANY lane of the other half.  For M = 1, 2, 4, 8 that is
+// a DPP lane pattern inside a row of 16 (quad permutes, then the mirrors), which costs a VALU
+// modifier instead of a trip through the LDS crossbar; wider steps use the generic shuffle.
+template <uint32_t CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <uint32_t M>
+__device__ __forceinline__ uint32_t other_half(uint32_t v) {
+    if constexpr (M == 1) return dpp_u32<0xB1>(v);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_u32<0x4E>(v);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return dpp_u32<0x141>(v);    // row_half_mirror
+    else if constexpr (M == 8) return dpp_u32<0x140>(v);    // row_mirror
+    else return (uint32_t)__shfl_xor((int)v, (int)M);
+}
+template <uint32_t M>
+__device__ __forceinline__ float other_half(float v) { return __uint_as_float(other_half<M>(__float_as_uint(v))); }
+template <uint32_t M>
+__device__ __forceinline__ int other_half(int v) { return (int)other_half<M>((uint32_t)v); }
+// f(M) for M = 1, 2, 4, ... < G
+template <uint32_t G, uint32_t M = 1, class Fn>
+__device__ __forceinline__ void butterfly(Fn &&f) {
+    if constexpr (M < G) {
+        f(std::integral_constant<uint32_t, M>());
+        butterfly<G, M * 2>(f);
+    }
+}
 template <uint32_t G>
 __device__ __forceinline__ float group_max_by_abs(const float *x, uint32_t n) {
     // local fold, first to last; NaN never selected (the fold starts from +0.0)
@@ -88,21 +128,19 @@ __device__ __forceinline__ float group_max_by_abs(const float *x, uint32_t n) {
     for (uint32_t k = 0; k < n; ++k)
         if (fabsf(x[k]) > fabsf(best)) best = x[k];
     const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (uint32_t m = 1; m < G; m <<= 1) {
-        float other = __shfl_xor(best, m);
-        // the partner with the lower lane number holds earlier elements
-        float early = (lane & m) ? other : best, late = (lane & m) ? best : other;
+    butterfly<G>([&](auto m) {
+        float other = other_half<m.value>(best);
+        // the half with the lower lane numbers holds earlier elements
+        float early = (lane & m.value) ? other : best, late = (lane & m.value) ? best : other;
         best = fabsf(late) > fabsf(early) ? late : early;
-    }
+    });
     return best;
 }
 template <uint32_t G>
 __device__ __forceinline__ float group_max_abs(const float *x, uint32_t n) {
     float m = 0.0f;
     for (uint32_t k = 0; k < n; ++k) { float a = fabsf(x[k]); m = a > m ? a : m; }   // acc.max(|x|), NaN ignored
-#pragma unroll
-    for (uint32_t s = 1; s < G; s <<= 1) { float o = __shfl_xor(m, s); m = o > m ? o : m; }
+    butterfly<G>([&](auto s) { float o = other_half<s.value>(m); m = o > m ? o : m; });
     return m;
 }
 // min and max in the total order (-0 < +0) with NaN ignored, folded from (f32::MAX, f32::MIN)
@@ -123,24 +161,21 @@ __device__ __forceinline__ void group_min_max(const float *x, uint32_t n, float 
         klo = min(klo, nan ? 0x7FFFFFFF : key);
         khi = max(khi, nan ? (int)0x80000000 : key);
     }
-#pragma unroll
-    for (uint32_t s = 1; s < G; s <<= 1) {
-        klo = min(klo, __shfl_xor(klo, s));
-        khi = max(khi, __shfl_xor(khi, s));
-    }
+    butterfly<G>([&](auto s) {
+        klo = min(klo, other_half<s.value>(klo));
+        khi = max(khi, other_half<s.value>(khi));
+    });
     lo = from_order_key(klo);
     hi = from_order_key(khi);
 }
 template <uint32_t G>
 __device__ __forceinline__ uint32_t group_or(uint32_t v) {
-#pragma unroll
-    for (uint32_t s = 1; s < G; s <<= 1) v |= __shfl_xor(v, s);
+    butterfly<G>([&](auto s) { v |= other_half<s.value>(v); });
     return v;
 }
 template <uint32_t G>
 __device__ __forceinline__ int group_add(int v) {
-#pragma unroll
-    for (uint32_t s = 1; s < G; s <<= 1) v += __shfl_xor(v, s);
+    butterfly<G>([&](auto s) { v += other_half<s.value>(v); });
     return v;
 }
 
@@ -160,7 +195,11 @@ __device__ __forceinline__ void pack_nibbles(const uint32_t *q, uint32_t gl, uin
         w[j] = (q[4 * j] & 0xFu) | ((q[4 * j + 1] & 0xFu) << 8) | ((q[4 * j + 2] & 0xFu) << 16) | ((q[4 * j + 3] & 0xFu) << 24);
 #pragma unroll
     for (uint32_t j = 0; j < W; ++j) {
-        uint32_t hi = __shfl_xor(w[j], G / 2);
+        // the word of the lane G/2 above (only the lower half of the group uses it)
+        uint32_t hi;
+        if constexpr (G == 4) hi = dpp_u32<0x4E>(w[j]);          // quad_perm [2,3,0,1]
+        else if constexpr (G == 8) hi = dpp_u32<0x104>(w[j]);    // row_shl:4
+        else hi = (uint32_t)__shfl_xor((int)w[j], (int)(G / 2));
         if (write && gl < G / 2) st32_a2(payload + gl * EPL + 4 * j, w[j] | (hi << 4));
     }
 }
@@ -292,7 +331,7 @@ struct EncQ8_0 {
         } else {
             float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_i8(roundf(__fmul_rn(x[k], recip)));
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_i8(round_away(__fmul_rn(x[k], recip)));
         }
         if (write) {
             if (gl == 0) st16(blk, hdr);
@@ -317,7 +356,7 @@ struct EncQ8_1 {
         } else {
             delta = __fdiv_rn(amax, 127.0f);
             float recip = __fdiv_rn(1.0f, delta);
-            for (uint32_t k = 0; k < EPL; ++k) { q[k] = sat_i8(roundf(__fmul_rn(x[k], recip))); part += q[k]; }
+            for (uint32_t k = 0; k < EPL; ++k) { q[k] = sat_i8(round_away(__fmul_rn(x[k], recip))); part += q[k]; }
         }
         int sum = group_add<G>(part);
         if (write) {
@@ -343,7 +382,7 @@ struct EncQ8K {
             float delta = __fdiv_rn(max, -127.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
             for (uint32_t k = 0; k < EPL; ++k) {
-                q[k] = sat_i8(min_c(roundf(__fmul_rn(x[k], recip)), 127.0f));
+                q[k] = sat_i8(min_c(round_away(__fmul_rn(x[k], recip)), 127.0f));
                 part += q[k];
             }
         }
