@@ -160,3 +160,82 @@ def test_open_errors(tmp_path):
     with pytest.raises(G.GGufError) as e:
         G.GGuf(tmp_path / "bad.gguf")
     assert e.value.kind == "MagicMismatch"
+
+
+# ---- hostile input: the parser must answer with an error code, never crash ----------------------
+
+def _valid_file():
+    rng = np.random.default_rng(9)
+    tensors = [("token_embd.weight", 1, [64, 8], rng.integers(0, 256, 64 * 8 * 2, dtype=np.uint8)),
+               ("blk.0.attn_q.weight", 12, [256, 4], rng.integers(0, 256, 4 * 144, dtype=np.uint8)),
+               ("blk.0.norm.weight", 0, [64], rng.integers(0, 256, 256, dtype=np.uint8))]
+    meta = {"general.architecture": "llama", "llama.block_count": 1, "tokens": ["a", "bc", "def"],
+            "scores": [0.5, 1.5], "general.alignment": 64, "flag": True, "big": (10, 2 ** 40)}
+    return np.frombuffer(G.build_gguf(meta, tensors), dtype=np.uint8).copy()
+
+
+def test_truncations_never_crash():
+    buf = _valid_file()
+    with G.GGuf.from_bytes(buf) as g:
+        n_ok = len(g.tensors)
+    assert n_ok == 3
+    for cut in range(0, buf.size):
+        try:
+            with G.GGuf.from_bytes(buf[:cut].copy()) as g:
+                assert len(g.tensors) == 3          # only the data region may be short
+        except G.GGufError as e:
+            assert e.kind in ("Eos", "MagicMismatch"), (cut, e.kind)
+
+
+def test_byte_flips_never_crash():
+    from hypothesis import given, settings, strategies as st
+    buf = _valid_file()
+    header_len = int(np.flatnonzero(buf[:-4] != 0).max()) if False else 600
+
+    @settings(max_examples=400, deadline=None, derandomize=True)
+    @given(st.lists(st.tuples(st.integers(0, header_len - 1), st.integers(0, 255)), min_size=1, max_size=6))
+    def run(flips):
+        b = buf.copy()
+        for pos, val in flips:
+            b[pos] = val
+        try:
+            with G.GGuf.from_bytes(b) as g:
+                for t in g.tensors:
+                    if t.ptr:
+                        t.bytes()[:1]              # what it hands out must be readable
+                g.keys()
+        except G.GGufError:
+            pass
+        except UnicodeDecodeError:
+            pass
+
+    run()
+
+
+def _hdr(n_tensors, n_kv):
+    return b"GGUF" + struct.pack("<IQQ", 3, n_tensors, n_kv)
+
+
+def _s(b):
+    return struct.pack("<Q", len(b)) + b
+
+
+@pytest.mark.parametrize("blob", [
+    _hdr(2 ** 60, 0),                                                     # absurd tensor count, nothing follows
+    _hdr(0, 2 ** 63),                                                     # absurd key/value count
+    _hdr(0, 1) + struct.pack("<Q", 2 ** 63) + b"k",                       # key length beyond the buffer
+    _hdr(0, 1) + _s(b"k") + struct.pack("<I", 8) + struct.pack("<Q", 2 ** 64 - 1),          # string value length
+    _hdr(0, 1) + _s(b"k") + struct.pack("<IIQ", 9, 4, 2 ** 62),           # array of 2^62 u32
+    _hdr(0, 1) + _s(b"k") + struct.pack("<IIQ", 9, 9, 1) * 40,            # arrays nested 40 deep, then nothing
+    _hdr(1, 0) + _s(b"t") + struct.pack("<I", 2 ** 32 - 1),               # 2^32-1 dimensions
+    _hdr(1, 0) + _s(b"t") + struct.pack("<IQQIQ", 2, 2 ** 40, 2 ** 40, 0, 0),               # shape product overflows
+    _hdr(1, 0) + _s(b"t") + struct.pack("<IQIQ", 1, 32, 2, 2 ** 64 - 8),  # offset near 2^64
+])
+def test_hostile_headers(blob):
+    buf = np.frombuffer(blob, dtype=np.uint8).copy()
+    try:
+        with G.GGuf.from_bytes(buf) as g:
+            for t in g.tensors:
+                assert t.ptr is None        # nothing of these can be backed by the buffer
+    except G.GGufError as e:
+        assert e.kind in ("Eos", "ValueType", "Invalid")
