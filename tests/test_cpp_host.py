@@ -35,3 +35,14 @@ def test_ggus_mirror_program():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ggus api ok" in r.stdout
+
+
+def test_container_code_under_host_sanitizers():
+    """Reader and writer built with AddressSanitizer + UBSan (host code only): the mirror's test
+    program, then 20000 mutated files through the parser."""
+    host = os.path.join(ROOT, "gguf_amd", "host")
+    r = subprocess.run(["make", "-C", host, "--no-print-directory", "asan"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "fsanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ggus api ok" in r.stdout and "fuzz ok" in r.stdout
