@@ -394,11 +394,13 @@ class Content:
     # ---- writing ------------------------------------------------------------------------------
 
     def write_files(self, out_dir, stem, max_tensor_count=2 ** 63, max_file_size=2 ** 63, no_tensor_first=False,
-                    write_data=True, device=0, rank=0, world=1):
+                    write_data=True, device=0, rank=0, world=1, max_parallel=4):
         """Content::write_files (write.rs:5-100): plan shards, then one writer thread per shard.
         Returns [(path, n_tensors, n_meta_kvs, n_bytes)] (FileInfo).
         With world > 1 (one process per GPU) every rank plans the same shards and writes those with
-        index % world == rank on its own device; no data moves between ranks."""
+        index % world == rank on its own device; no data moves between ranks.
+        At most `max_parallel` shards are in flight at once (each holds two pinned buffers of its
+        largest lazy tensor); the reference starts all shard threads together."""
         names = list(self.tensors)
         kvs = [(k, ty, raw) for k, (ty, raw) in self.meta_kvs.items()]
         shard_of, n_shards = plan_shards(self.alignment, kvs, [(n, self.tensors[n].ty, self.tensors[n].shape)
@@ -412,11 +414,14 @@ class Content:
                  for i in range(n_shards)]
         results, errors = [None] * n_shards, []
 
+        gate = threading.Semaphore(max(1, max_parallel))
+
         def run(i):
-            try:
-                results[i] = self._write_shard(i, paths[i], shards[i], kvs, write_data, device)
-            except BaseException as e:      # reported by the caller's thread
-                errors.append(e)
+            with gate:
+                try:
+                    results[i] = self._write_shard(i, paths[i], shards[i], kvs, write_data, device)
+                except BaseException as e:      # reported by the caller's thread
+                    errors.append(e)
 
         threads = [threading.Thread(target=run, args=(i,)) for i in range(n_shards) if i % world == rank]
         for th in threads:
