@@ -1,5 +1,5 @@
 """End to end on the GPU: a GGUF file on disk -> mmap reader -> streamed decode -> device tensors,
-checked against the oracle (BASELINE configs 0 and 2 in miniature: a TinyLlama-shaped layer set
+checked against the oracle (the benchmark's first and third configurations in miniature: a TinyLlama-shaped layer set
 under the Q4_K_M mixture, plus legacy and 16-bit tensors)."""
 import numpy as np
 import pytest

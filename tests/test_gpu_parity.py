@@ -215,7 +215,7 @@ def test_streamed_context(torch_cuda, oracle):
 
 
 def test_q4_0_4096_square(torch_cuda, oracle):
-    """BASELINE config: a single 4096 x 4096 Q4_0 tensor, packed by the reference's quantizer rule."""
+    """Benchmark configuration: a single 4096 x 4096 Q4_0 tensor, packed by the reference's quantizer rule."""
     rng = np.random.default_rng(0xC0FFEE02)
     x = (rng.standard_normal(4096 * 4096) * 0.02).astype(np.float32)
     p = oracle.quantize(2, x)

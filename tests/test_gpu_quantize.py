@@ -170,7 +170,7 @@ def test_host_entry_point(torch_cuda, oracle, ty):
 
 
 def test_tinyllama_f16_to_q8_0_round_trip(torch_cuda, oracle):
-    """BASELINE config 0 on the GPU: F16 tensor -> Q8_0 -> F32, on one TinyLlama-shaped
+    """The benchmark's CPU-runnable configuration on the GPU: F16 tensor -> Q8_0 -> F32, on one TinyLlama-shaped
     tensor (attn_output [2048, 2048]) with seeded F16 payload (the shipped file has none)."""
     import gguf_amd as g
     t = torch_cuda

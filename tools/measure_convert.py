@@ -1,6 +1,6 @@
 """End-to-end rate of the convert pipeline (map input, decode on the GPU, D2H, write the output file):
 a synthetic llama-shaped Q4_K file cast to F32.  File I/O inclusive, so far below the kernel's rate;
-reported for DESIGN.md, never the benchmark's `value`.
+reported beside the kernel numbers, never the benchmark's `value`.
 Run on the GPU box: python tools/measure_convert.py [out_dir ...]   (default /dev/shm and /tmp)
 """
 import json

@@ -1,4 +1,4 @@
-"""Rates of the two entry points that cross PCIe, for DESIGN.md (never the benchmark's `value`):
+"""Rates of the two entry points that cross PCIe, (reported beside the kernel numbers, never the benchmark's `value`):
   host -> host   ggq_dequantize_slice   (packed in, decoded out, both over PCIe)
   host -> device ggq_dequantize_async   (only the packed bytes cross; decoded tensor stays in HBM)
 Run on the GPU box: python tools/measure_host_paths.py
