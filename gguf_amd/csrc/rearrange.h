@@ -33,7 +33,9 @@ __global__ __launch_bounds__(WG_THREADS) void permute_qk_rows(uint8_t *__restric
         const uint64_t a = in_head & 1, b = in_head >> 1;
         const uint64_t srow = head * dh + a * (dh / 2) + b;
         if constexpr (VEC == 16) {
-            *(uint4v *)(dst + row * row_bytes + col * 16) = *(const uint4v *)(src + srow * row_bytes + col * 16);
+            // read once, written once: non-temporal both ways
+            const uint4v v = __builtin_nontemporal_load((const uint4v *)(src + srow * row_bytes + col * 16));
+            __builtin_nontemporal_store(v, (uint4v *)(dst + row * row_bytes + col * 16));
         } else if constexpr (VEC == 4) {
             *(uint32_t *)(dst + row * row_bytes + col * 4) = *(const uint32_t *)(src + srow * row_bytes + col * 4);
         } else if constexpr (VEC == 2) {

@@ -21,6 +21,7 @@
 #include "kernels_v2.h"
 #include "quantize.h"
 #include "schedule.h"
+#include "rearrange.h"
 
 using namespace ggq;
 
@@ -557,6 +558,18 @@ int main(int argc, char **argv) {
         vs.push_back({"narrow f32 -> bf16", (double)elems * 6, [=](hipStream_t s) {
                           hipLaunchKernelGGL((narrow_vec<InF32, OutBF16>), dim3(gridn), dim3(WG_THREADS), 0, s,
                                              (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+    }
+    {   // row gather of permute_qk over opaque packed rows: [4096 x rows] Q4_K (2304-byte rows) and F16 (8192-byte rows)
+        for (uint64_t rb : {2304ull, 8192ull}) {
+            const uint64_t rows = (elems * 2 / rb) / 256 * 256, dh = 128;
+            const uint64_t pieces = rb / 16 * rows, per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+            const unsigned grid = (unsigned)((pieces + per_wg - 1) / per_wg);
+            char label[64];
+            std::snprintf(label, sizeof label, "permute_qk rows of %llu bytes", (unsigned long long)rb);
+            vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(WG_THREADS), 0, s,
+                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh); }, {}});
+        }
     }
     QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
     QNT(EncQ4_1, InF32, "quant Q4_1 from f32")
