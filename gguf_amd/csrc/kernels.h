@@ -199,7 +199,10 @@ __device__ __forceinline__ void deq_tile(uint4v *lds, const uint8_t *src, uint32
 // ---- one tensor per launch: workgroup b decodes tile b ---------------------------
 // The grid covers every tile (no loop): the hardware dispatches workgroups in
 // order, so at any moment the in-flight stores cover one compact, steadily advancing
-// window of the output -- the access pattern HBM serves best.
+// window of the output -- the access pattern HBM serves best.  (An XCD-aware order, in which each
+// XCD takes C = 2..64 consecutive tiles so that the boundary lines two tiles share meet in one L2,
+// measured equal for C <= 4 and 1-10 % slower beyond, also for the formats whose tiles do not end
+// on 128-byte lines: the shared lines already come from the memory-side cache.)
 template <class F, class O, bool NT, bool NTL = false>
 __global__ __launch_bounds__(WG_THREADS) void deq_one(const uint8_t *__restrict__ src,
                                                       typename O::T *__restrict__ dst,
