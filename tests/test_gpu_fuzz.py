@@ -11,7 +11,10 @@ from util import same_bits
 pytestmark = pytest.mark.gpu
 
 QUANT_TYPES = [1, 30, 2, 3, 6, 7, 8, 9, 15]
-_cfg = dict(max_examples=120, deadline=None, derandomize=True,
+import os  # noqa: E402
+
+# GGQ_FUZZ_EXAMPLES=2000 for a longer one-off run
+_cfg = dict(max_examples=int(os.environ.get("GGQ_FUZZ_EXAMPLES", "120")), deadline=None, derandomize=True,
             suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
