@@ -174,7 +174,11 @@ void ggq_batch_destroy(ggq_batch *batch);
  * (pageable or pinned) in chunks and decodes each chunk on the device as soon
  * as it lands, copy and decode overlapping; the decoded tensor stays in device
  * memory at d_dst.  The call returns once the last chunk has been staged;
- * ggq_sync waits for everything enqueued.  No counterpart in the reference;
+ * ggq_sync waits for everything enqueued.  A page-locked source (hipHostMalloc /
+ * hipHostRegister) is read in place by the DMA engine, without staging, and must
+ * therefore stay valid until ggq_sync; a pageable source may be reused as soon as
+ * the call returns.  d_dst is written on the context's own streams.  No counterpart
+ * in the reference;
  * this is the whole-model conversion path (one context per GPU, tensors dealt
  * to GPUs by an index partition). */
 typedef struct ggq_ctx ggq_ctx;
