@@ -35,6 +35,15 @@ constexpr bool kNT = GGQ_NT_STORES != 0;
 
 thread_local std::string g_err;
 
+// GGQ_NO_PREFETCH=1 switches the burst prefetch off (a measurement knob, read once)
+Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
+    static const bool off = [] {
+        const char *e = std::getenv("GGQ_NO_PREFETCH");
+        return e && *e && *e != '0';
+    }();
+    return off ? Prefetch{0, 0} : prefetch_for(ty, out_ty, batch);
+}
+
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -139,7 +148,7 @@ ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t b
             hipLaunchKernelGGL((deq_one<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
                                (const uint8_t *)d_src + t0 * G::TBYTES,                       \
                                (typename O::T *)d_dst + t0 * G::ELEMS, blocks - t0 * G::TB,   \
-                               prefetch_for(ID, out_id<O>(), false));                         \
+                               pick_prefetch(ID, out_id<O>(), false));                        \
         }                                                                                     \
         break;                                                                                \
     }
@@ -278,7 +287,7 @@ ggq_status launch_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hi
         for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                     \
             uint64_t n = std::min(kMaxGrid, ntiles - t0);                                        \
             hipLaunchKernelGGL((deq_batch<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
-                               d_table + t0, n, prefetch_for(ID, out_id<O>(), true));           \
+                               d_table + t0, n, pick_prefetch(ID, out_id<O>(), true));          \
         }                                                                                        \
         break;
         GGQ_FORMATS(X)
