@@ -35,13 +35,23 @@ constexpr bool kNT = GGQ_NT_STORES != 0;
 
 thread_local std::string g_err;
 
-// GGQ_NO_PREFETCH=1 switches the burst prefetch off (a measurement knob, read once)
+// Measurement knobs, read once: GGQ_NO_PREFETCH=1 switches the burst prefetch off,
+// GGQ_PREFETCH="period,lead" replaces the schedule of every kernel.
 Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
-    static const bool off = [] {
+    static const int mode = [] {
         const char *e = std::getenv("GGQ_NO_PREFETCH");
-        return e && *e && *e != '0';
+        if (e && *e && *e != '0') return 1;
+        e = std::getenv("GGQ_PREFETCH");
+        return e && *e ? 2 : 0;
     }();
-    return off ? Prefetch{0, 0} : prefetch_for(ty, out_ty, batch);
+    static const Prefetch forced = [] {
+        Prefetch p{0, 0};
+        if (const char *e = std::getenv("GGQ_PREFETCH")) std::sscanf(e, "%u,%u", &p.period, &p.lead);
+        return p;
+    }();
+    if (mode == 1) return Prefetch{0, 0};
+    if (mode == 2) return forced;
+    return prefetch_for(ty, out_ty, batch);
 }
 
 bool hip_ok(hipError_t e, const char *what) {

@@ -19,9 +19,10 @@ from gguf_amd.quants import GGmlType  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     evict = torch.zeros(2 << 28, dtype=torch.int32, device=dev)    # 2 GiB
-    tag = "prefetch off" if os.environ.get("GGQ_NO_PREFETCH") else "prefetch on "
+    tag = "prefetch off" if os.environ.get("GGQ_NO_PREFETCH") else "prefetch " + os.environ.get("GGQ_PREFETCH", "on ")
+    sizes = [int(x) for x in os.environ.get("PROBE_SIZES", "4,16,45,128,512").split(",")]
     for ty in (GGmlType.Q4K, GGmlType.Q6K):
-        for mi in (4, 16, 45, 128, 512):
+        for mi in sizes:
             n = mi << 20
             src = synth.random_blocks_device(ty, n // 256, 3, dev)
             dst = torch.empty(n, dtype=torch.float32, device=dev)
