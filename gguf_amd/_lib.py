@@ -17,7 +17,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libggq.so")
 
-OK, INDIVISIBLE, LENGTH_MISMATCH, UNSUPPORTED, DEVICE, MISALIGNED, INVALID = range(7)
+OK, INDIVISIBLE, LENGTH_MISMATCH, UNSUPPORTED, DEVICE, MISALIGNED, INVALID, TOO_LARGE = range(8)
 
 
 class ggq_tensor(ctypes.Structure):
@@ -70,6 +70,7 @@ SYMBOLS = {
     "ggq_batch_destroy": (None, [_vp]),
     "ggq_ctx_create": (_int, [_int, _sz, ctypes.POINTER(_vp)]),
     "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),
+    "ggq_dequantize_noalloc": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
     "ggq_sync": (_int, [_vp]),
     "ggq_ctx_destroy": (None, [_vp]),
     "ggq_gguf_parse": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),

@@ -24,6 +24,12 @@
 
 using namespace ggq;
 
+// Device staging buffer of ggq_dequantize_noalloc: one copy per GPU the library is loaded on,
+// held until the process ends.  The name is only a host-side handle; the device address of each
+// GPU's copy comes from hipGetSymbolAddress (noalloc_state below).  The 256 spare bytes cover the
+// decode kernels' 16-byte loads, which may run up to 15 bytes past the last block.
+static __device__ __align__(256) uint8_t scratch[GGQ_NOALLOC_MAX_BYTES + 256];
+
 namespace {
 
 // Non-temporal stores for the decoded output: it is written once and never
@@ -531,6 +537,36 @@ void pool_put(ggq_ctx *c) {
 
 }  // namespace
 
+// ---- per-device state of ggq_dequantize_noalloc ------------------------------------
+namespace {
+constexpr int kNoallocMaxDevices = 64;
+struct NoallocDev {
+    void *ptr = nullptr;   // device address of this GPU's copy of `scratch`
+    int cus = 0;
+};
+std::mutex g_noalloc_mu;
+NoallocDev g_noalloc[kNoallocMaxDevices];
+
+// Resolves, once per device and with that device current, where its copy of `scratch` lives.
+ggq_status noalloc_state(int dev, NoallocDev &out) {
+    if (dev < 0 || dev >= kNoallocMaxDevices) { g_err = "device index out of range"; return GGQ_DEVICE; }
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    NoallocDev &d = g_noalloc[dev];
+    if (d.ptr == nullptr) {
+        void *p = nullptr;
+        int cus = 0;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (p == nullptr || (uintptr_t)p % 256 != 0) { g_err = "scratch symbol did not resolve"; return GGQ_DEVICE; }
+        d.cus = cus > 0 ? cus : 256;
+        d.ptr = p;
+    }
+    out = d;
+    return GGQ_OK;
+}
+}  // namespace
+
+
 // =================================== C ABI =======================================
 extern "C" {
 
@@ -579,6 +615,7 @@ const char *ggq_status_str(ggq_status st) {
     case GGQ_DEVICE: return "HIP device error";
     case GGQ_MISALIGNED: return "device pointer is not aligned as required";
     case GGQ_INVALID: return "invalid argument";
+    case GGQ_TOO_LARGE: return "input exceeds the fixed capacity of this entry point";
     }
     return "unknown status";
 }
@@ -971,6 +1008,37 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
     }
     (void)hipSetDevice(prev);
     return rc;
+}
+
+// ---- streamed host -> device, no allocation -----------------------------------------
+ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, size_t dst_elems, const void *h_src,
+                                  size_t src_blocks, void *hip_stream) {
+    ggq_status st = check_slice(ty, out_ty, dst_elems, src_blocks);
+    if (st != GGQ_OK) return st;
+    if (src_blocks == 0) return GGQ_OK;
+    if (!d_dst || !h_src) return GGQ_INVALID;
+    if ((uintptr_t)d_dst % 16 != 0) return GGQ_MISALIGNED;
+    const TypeInfo *ti = type_info(ty);
+    if (src_blocks > (size_t)GGQ_NOALLOC_MAX_BYTES / ti->bytes) {
+        g_err = "ggq_dequantize_noalloc: packed input exceeds GGQ_NOALLOC_MAX_BYTES";
+        return GGQ_TOO_LARGE;
+    }
+    // Only page-locked memory goes to the device without the runtime staging (and possibly
+    // allocating) on the way.
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, h_src) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        g_err = "ggq_dequantize_noalloc: h_src is not page-locked host memory";
+        return GGQ_INVALID;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    NoallocDev nd;
+    st = noalloc_state(dev, nd);
+    if (st != GGQ_OK) return st;
+    hipStream_t q = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemcpyAsync(nd.ptr, h_src, src_blocks * ti->bytes, hipMemcpyHostToDevice, q));
+    return launch_out(ty, out_ty, d_dst, nd.ptr, src_blocks, nd.cus, q);
 }
 
 ggq_status ggq_sync(ggq_ctx *c) {

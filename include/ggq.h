@@ -35,7 +35,8 @@ typedef enum ggq_status {
     GGQ_UNSUPPORTED = 3,     /* type id has no decoder (IQ1/IQ2/IQ3 codebook types, Q4_0_x_x, integers) */
     GGQ_DEVICE = 4,          /* HIP runtime error or no device; see ggq_last_error() */
     GGQ_MISALIGNED = 5,      /* device pointer alignment requirement not met */
-    GGQ_INVALID = 6          /* null pointer / bad argument */
+    GGQ_INVALID = 6,         /* null pointer / bad argument */
+    GGQ_TOO_LARGE = 7        /* input beyond the fixed capacity of ggq_dequantize_noalloc */
 } ggq_status;
 
 enum {
@@ -188,6 +189,28 @@ ggq_status ggq_dequantize_async(ggq_ctx *ctx, uint32_t ggml_type, uint32_t out_t
                                 const void *h_src, size_t src_blocks);
 ggq_status ggq_sync(ggq_ctx *ctx);
 void ggq_ctx_destroy(ggq_ctx *ctx);
+
+/* ---- streamed host -> device decode that allocates nothing ------------------
+ * No counterpart in the reference.  For callers that cannot call hipMalloc: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid allocation.  Does what one
+ * ggq_dequantize_async call does -- packed blocks travel from host memory to a device staging
+ * buffer, the decode kernel reads them there and writes d_dst -- but needs no context: the
+ * staging buffer is a fixed device array of GGQ_NOALLOC_MAX_BYTES inside the library (every
+ * GPU the library runs on holds one until the process ends), the copy and the kernel are
+ * enqueued on `hip_stream` (NULL = default stream) and the call does not synchronize.  It calls
+ * no hipMalloc / hipFree and creates no stream or event.
+ * h_src must be page-locked host memory (hipHostMalloc / hipHostRegister; GGQ_INVALID
+ * otherwise) and stay valid until the stream has passed the copy; src_blocks * block bytes
+ * must not exceed GGQ_NOALLOC_MAX_BYTES (GGQ_TOO_LARGE otherwise -- split the tensor).
+ * Otherwise the contract and the check order of ggq_dequantize_device apply (d_dst 16-byte aligned).
+ * All calls on one GPU share that GPU's staging buffer: calls on the same stream are ordered
+ * by the stream; calls that can overlap on one GPU (different streams, or several threads)
+ * race on it and must be serialized by the caller. */
+#define GGQ_NOALLOC_MAX_BYTES (32u << 20)
+ggq_status ggq_dequantize_noalloc(uint32_t ggml_type, uint32_t out_type,
+                                  void *d_dst, size_t dst_elems,
+                                  const void *h_src, size_t src_blocks,
+                                  void *hip_stream);
 
 #ifdef __cplusplus
 }
