@@ -149,3 +149,33 @@ def workload_bytes(items, out_bytes=4):
     pin = sum(n // block_elems(ty) * block_bytes(ty) for _, ty, n in items)
     el = sum(n for _, _, n in items)
     return pin, el * out_bytes, el
+
+
+def sample_blocks(tensors, count, seed):
+    """Draws `count` random blocks (uniformly over all blocks) from device-resident tensors of ONE block
+    type and returns (packed bytes, decoded values) of exactly those blocks as numpy arrays on the host:
+    the material for checking a large decode against a CPU decoder without decoding everything there.
+
+    tensors: [(ggml_type, src uint8 device tensor, dst device tensor)]; 16-bit outputs come back as
+    uint16 bit patterns."""
+    import torch
+    ty = GGmlType(int(tensors[0][0]))
+    bb, n = block_bytes(ty), block_elems(ty)
+    counts = np.array([t[1].numel() // bb for t in tensors], dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    picks = np.sort(rng.integers(0, int(counts.sum()), size=count))
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    which = np.searchsorted(starts, picks, side="right") - 1
+    packed, decoded = [], []
+    for ti in np.unique(which):
+        idx = torch.from_numpy(picks[which == ti] - starts[ti]).to(tensors[ti][1].device)
+        _, src, dst = tensors[ti]
+        packed.append(src.view(-1, bb).index_select(0, idx).cpu().numpy().reshape(-1))
+        d = dst.view(-1, n).index_select(0, idx)
+        if d.element_size() == 2:
+            d = d.view(torch.int16)
+        decoded.append(d.cpu().numpy().reshape(-1))
+    dec = np.concatenate(decoded)
+    if dec.dtype == np.int16:
+        dec = dec.view(np.uint16)
+    return np.concatenate(packed), dec

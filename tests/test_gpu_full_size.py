@@ -1,0 +1,100 @@
+"""The benchmark configurations at full size, through the batch path (ggq_batch_*), checked with
+properties that do not need the CPU oracle to decode everything:
+
+  (a) every tensor: the batch output equals, bit for bit and under a random permutation of the blocks,
+      what the single-tensor kernel gives for the permuted blocks (the decode is a pure function of the
+      block, and the tile table / geometry of the batch places every block's output correctly);
+  (b) 4096 random blocks per block type against the oracle, bit for bit.
+"""
+import numpy as np
+import pytest
+
+from util import same_bits, same_bits16, first_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+def run_workload(t, oracle, name, out):
+    import gguf_amd as g
+    from gguf_amd import synth
+    from gguf_amd.quants import GGmlType, block_bytes, block_elems
+    items = synth.workload(name)
+    out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    ob = 4 if out == "f32" else 2
+    pin, pout, elems = synth.workload_bytes(items, ob)
+    free = t.cuda.mem_get_info()[0]
+    if pin + pout + (4 << 30) > free:
+        pytest.skip(f"{name} -> {out} needs {(pin + pout) / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} GiB free")
+    dst_all = t.empty(elems, dtype=out_dt, device="cuda")
+    # poison: a NaN pattern that no decode of these inputs produces
+    if ob == 2:
+        dst_all.view(t.int16).fill_(0x7FC1)
+    else:
+        dst_all.view(t.int32).fill_(0x7FC00001)
+    tensors, at = [], 0
+    for i, (_, ty, ne) in enumerate(items):
+        src = synth.random_blocks_device(ty, ne // block_elems(ty), 0xC0FFEE00 + i, "cuda")
+        tensors.append((ty, src, dst_all[at:at + ne]))
+        at += ne
+    out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out]
+    b = g.Batch(tensors, out_ty)
+    types = sorted({int(ty) for ty, _, _ in tensors})
+    assert b.launches == len(types)
+    b.run()
+    t.cuda.synchronize()
+    # (a) per tensor, against the single-tensor kernel on permuted blocks
+    gen = t.Generator(device="cuda")
+    gen.manual_seed(1234)
+    for k, (ty, src, dst) in enumerate(tensors):
+        bb, n = block_bytes(ty), block_elems(ty)
+        blocks = src.numel() // bb
+        perm = t.randperm(blocks, device="cuda", generator=gen)
+        src2 = src.view(blocks, bb)[perm].contiguous().view(-1)
+        dst2 = t.empty_like(dst)
+        g.dequantize_slice(ty, dst2, src2)
+        it = t.int32 if ob == 4 else t.int16
+        same = t.equal(dst.view(blocks, n)[perm].view(it), dst2.view(blocks, n).view(it))
+        assert same, f"{name}: tensor {k} ({items[k][0]}, type {int(ty)}) differs between batch and single kernel"
+        del src2, dst2, perm
+    # (b) sampled blocks against the oracle
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    for ty in types:
+        group = [x for x in tensors if int(x[0]) == ty]
+        packed, got = synth.sample_blocks(group, 4096, 99 + ty)
+        want = oracle.dequantize(ty, packed, o_out, threads=8)
+        if out == "f32":
+            assert same_bits(got, want), (name, ty, first_diff(got, want))
+        else:
+            assert same_bits16(got, want, out), (name, ty, first_diff(got, want))
+    b.close()
+    return len(tensors), elems
+
+
+@pytest.mark.parametrize("fmt", ["q2_k", "q3_k", "q4_k", "q5_k", "q6_k"])
+def test_llama7b_every_k_quant(torch_cuda, oracle, fmt):
+    """Llama-7B shapes, 226 tensors / 6.74 G elements, each K-quant in turn, f32 output."""
+    n, elems = run_workload(torch_cuda, oracle, "llama7b_" + fmt, "f32")
+    assert (n, elems) == (226, 6_738_149_376)
+
+
+def test_llama7b_q4_k_m(torch_cuda, oracle):
+    """The configuration the benchmark's headline is quoted on."""
+    run_workload(torch_cuda, oracle, "llama7b_q4_k_m", "f32")
+
+
+def test_tinyllama_q4_k_m(torch_cuda, oracle):
+    run_workload(torch_cuda, oracle, "tinyllama_q4_k_m", "bf16")
+
+
+def test_llama70b_q4_k_m_iq4nl_f16(torch_cuda, oracle):
+    """Llama-70B shapes, 562 tensors / 68.98 G elements, Q4_K_M mixture with IQ4_NL for attn_k / attn_v,
+    f16 output (41 GB in + 138 GB out; the f32 form does not fit one GPU)."""
+    n, elems = run_workload(torch_cuda, oracle, "llama70b_q4_k_m_iq4nl", "f16")
+    assert elems == 68_975_329_280

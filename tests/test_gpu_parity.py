@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+import hand_kats
 from util import same_bits, same_bits16, first_diff
 
 pytestmark = pytest.mark.gpu
@@ -71,6 +72,28 @@ def test_kat_and_edge_scales(torch_cuda, oracle, ty):
     assert same_bits(got, e[f"t{ty}_f32"]), first_diff(got, e[f"t{ty}_f32"])
     got = gpu_decode(torch_cuda, ty, e[f"t{ty}_packed"], "f16")
     assert same_bits16(got, e[f"t{ty}_f16"], "f16")
+
+
+@pytest.mark.parametrize("case", hand_kats.cases(), ids=lambda c: f"type{c[0]}")
+def test_hand_derived_blocks(torch_cuda, case):
+    """Expected values typed in by hand (tests/hand_kats.py), not produced by any decoder; bit for bit,
+    through the single-tensor kernel and, repeated over several tiles, through the batch kernel."""
+    import gguf_amd as g
+    t = torch_cuda
+    ty, blk, want = case
+    got = gpu_decode(t, ty, blk)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), first_diff(got, want)
+    got16 = gpu_decode(t, ty, blk, "f16")
+    assert np.array_equal(got16, want.astype(np.float16).view(np.uint16))
+    reps = 3 * 8192 // g.block_elems(ty) + 1
+    src = t.from_numpy(np.tile(blk, reps)).cuda()
+    dst = t.empty(reps * want.size, dtype=t.float32, device="cuda")
+    b = g.Batch([(ty, src, dst)])
+    b.run()
+    t.cuda.synchronize()
+    got = dst.cpu().numpy().reshape(reps, want.size)
+    assert np.array_equal(got.view(np.uint32), np.tile(want.view(np.uint32), (reps, 1)))
+    b.close()
 
 
 # block counts around the tile sizes (a workgroup tile is 4096 elements for f32
@@ -193,6 +216,85 @@ def test_batch_matches_single(torch_cuda, oracle):
         for (ty, _, d), p in zip(tensors, packed):
             want = oracle.dequantize(ty, p, threads=8)
             assert same_bits(d.cpu().numpy(), want), (ty, first_diff(d.cpu().numpy(), want))
+    b.close()
+
+
+def _batch_case(t, oracle, ty, sizes, seed, out_dt, offsets=True):
+    """Builds tensors of `sizes` blocks of one type on the device; returns (tensor list, packed list)."""
+    from gguf_amd import synth
+    tensors, packed = [], []
+    for i, blocks in enumerate(sizes):
+        p = synth.random_blocks(ty, blocks, seed + i)
+        pad = (2 * i + 2 * (i // 8)) % 16 if offsets else 0       # different source alignments inside one launch
+        buf = t.empty(p.size + pad, dtype=t.uint8, device="cuda")
+        src = buf[pad:]
+        src.copy_(t.from_numpy(p))
+        dst = t.full((blocks * oracle.block_elems(ty),), -1.0, dtype=out_dt, device="cuda")
+        tensors.append((ty, src, dst))
+        packed.append(p)
+    return tensors, packed
+
+
+@pytest.mark.parametrize("ty", BLOCK_TYPES)
+@pytest.mark.parametrize("out", ["f32", "f16", "bf16"])
+def test_batch_every_format_and_output(torch_cuda, oracle, ty, out):
+    """The batch kernel (the one the benchmark times) for every block type and output type: more tiles
+    than lead + period of every burst-prefetch schedule (<= 2048 + 1536), so duty workgroups fire and look
+    far tiles up in the table; short tiles (a tensor's last) between whole ones, which the prefetch must
+    skip; mixed source alignments."""
+    import gguf_amd as g
+    t = torch_cuda
+    n = oracle.block_elems(ty)
+    tile = (4096 if out == "f32" else 8192) // n            # blocks per tile
+    sizes = [1500 * tile + 5, 1, 900 * tile, 7, tile - 1, 1300 * tile + 1, tile + 1, 33, 400 * tile, 2 * tile]
+    out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    tensors, packed = _batch_case(t, oracle, ty, sizes, 8100 + ty, out_dt)
+    b = g.Batch(tensors, {"f32": g.GGmlType.F32, "f16": g.GGmlType.F16, "bf16": g.GGmlType.BF16}[out])
+    assert b.launches == 1
+    b.run()
+    t.cuda.synchronize()
+    for (_, _, d), p in zip(tensors, packed):
+        want = oracle.dequantize(ty, p, o_out, threads=8)
+        if out == "f32":
+            got = d.cpu().numpy()
+            assert same_bits(got, want), (ty, p.size, first_diff(got, want))
+        else:
+            got = d.view(t.int16).cpu().numpy().view(np.uint16)
+            assert same_bits16(got, want, out), (ty, p.size, first_diff(got, want))
+    b.close()
+
+
+@pytest.mark.parametrize("out", ["f32", "f16", "bf16"])
+def test_batch_all_types_in_one_plan(torch_cuda, oracle, out):
+    """One plan holding every decodable type (14 block types + F16 + BF16 sources), interleaved."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    tensors, packed = [], []
+    for rnd in range(3):
+        for ty in ALL_TYPES:
+            n = oracle.block_elems(ty)
+            blocks = (3 + rnd) * 8192 // n + (rnd * 5 + ty) % 7 if n > 1 else 50001 + 4 * rnd + ty
+            ts, ps = _batch_case(t, oracle, ty, [blocks], 8300 + 31 * rnd + ty, out_dt, offsets=(n > 1))
+            tensors += ts
+            packed += ps
+    b = g.Batch(tensors, {"f32": g.GGmlType.F32, "f16": g.GGmlType.F16, "bf16": g.GGmlType.BF16}[out])
+    assert b.launches == len(BLOCK_TYPES) + 6            # one per block type + one per F16 / BF16 tensor
+    for _ in range(2):
+        for _, _, d in tensors:
+            d.fill_(-1.0)
+        b.run()
+        t.cuda.synchronize()
+        for (ty, _, d), p in zip(tensors, packed):
+            want = oracle.dequantize(ty, p, o_out, threads=8)
+            if out == "f32":
+                assert same_bits(d.cpu().numpy(), want), (ty, first_diff(d.cpu().numpy(), want))
+            else:
+                got = d.view(t.int16).cpu().numpy().view(np.uint16)
+                assert same_bits16(got, want, out), (ty, first_diff(got, want))
     b.close()
 
 

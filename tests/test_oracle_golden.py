@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import hand_kats
 import pyref
 from util import same_bits, same_bits16, first_diff
 
@@ -77,6 +78,21 @@ def test_kat_hand_values(oracle):
     blk[208:210] = [0x00, 0x3C]
     y = oracle.dequantize(14, blk)
     assert list(y[:16]) == [64.0] * 16 and list(y[16:32]) == [-32.0] * 16
+
+
+@pytest.mark.parametrize("case", hand_kats.cases(), ids=lambda c: f"type{c[0]}")
+def test_hand_derived_blocks(oracle, case):
+    """Expected values typed in by hand (tests/hand_kats.py): the 6-bit scale repacks with non-zero top bits,
+    qh / hmask bit walks, negative scales, all 16 IQ4 codes.  Compared bit for bit (also the sign of zero).
+    The same blocks must also pass through the naive Python restatement."""
+    ty, blk, want = case
+    got = oracle.dequantize(ty, blk)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), first_diff(got, want)
+    for out_ty, dt in ((oracle.F16, np.float16),):
+        got16 = oracle.dequantize(ty, blk, out_ty)
+        assert np.array_equal(got16, want.astype(dt).view(np.uint16))     # numpy narrows with round-to-nearest-even too
+    b = pyref.decode(ty, blk, oracle.block_bytes(ty))
+    assert np.array_equal(b.view(np.uint32), want.view(np.uint32)), first_diff(b, want)
 
 
 @pytest.mark.parametrize("ty", BLOCK_TYPES)
