@@ -2,27 +2,34 @@
 """Benchmark of the GGUF dequantize hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--out f32|f16|bf16]
+                    [--scaling strong|weak] [--streamed-steps S]
 
 One "step" decodes one whole synthetic tensor set that is already resident in HBM
 (packed blocks in, f32 out), through the C ABI (ggq_batch_run: one kernel launch
 per block type present).  Default workload: the Llama-7B-shaped tensor set under
 the Q4_K_M type mixture (6.74 G elements, 226 tensors, Q4_K + Q6_K).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the job is N such sets
-(weak scaling), dealt to the ranks by the index partition of gguf_amd.shard; no
-collective takes part in the data path, the process group is used for the barriers
-around the timed region and for the max-over-ranks of the time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): by default ONE such set is
+dealt to the ranks by the index partition of gguf_amd.shard (strong scaling: the way a
+whole-model conversion shards its tensors); `--scaling weak` gives every rank a whole set.
+No collective takes part in the data path; the process group (gloo, host tensors) carries
+only the barriers around the timed regions and the max-over-ranks of the times.
 
 Prints ONE JSON line on rank 0.  `value` = decoded (output) bytes of the whole job
-per second.  `roofline` prices the dominant kernel (the Q4_K launch) in algorithmic
-bytes = elements x (block_bytes/block_elems + sizeof(out)) against 8 TB/s, with the
-launch duration measured by HIP events on the launch stream inside the timed region.
-`cpu_baseline` times the CPU oracle (a port of the reference's per-block decode) on
-this box's host cores on a bounded sample of the same workload.
+per second, inputs resident in HBM.  `roofline` prices the dominant kernel (the Q4_K
+launch) in algorithmic bytes = elements x (block_bytes/block_elems + sizeof(out))
+against 8 TB/s, with the launch duration measured by HIP events on the launch stream
+inside the timed region.  `verified`: after the timed region, random blocks of every launch
+and their outputs are pulled back and compared bit for bit with the CPU oracle.
+`streamed` (a leg of its own, never `value`): the same share decoded from page-locked HOST
+memory through ggq_dequantize_async (H2D copy and decode overlapping on two streams) --
+end to end, PCIe-bound.  `cpu_baseline` times the CPU oracle (a port of the reference's
+per-block decode) on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0
+VERIFY_BLOCKS = 4096          # per launch plan (block type)
 
 
 def parse():
@@ -41,22 +49,66 @@ def parse():
                     help="untimed steps run for this long before the warm-up steps (clock ramp)")
     ap.add_argument("--workload", default="llama7b_q4_k_m")
     ap.add_argument("--out", default="f32", choices=["f32", "f16", "bf16"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank's share is one whole workload (default); strong: ONE workload "
-                         "split over the ranks (for sets that do not fit one GPU, e.g. llama70b_q4_k_m_iq4nl)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default): ONE workload split over the ranks by the index partition; "
+                         "weak: every rank's share is one whole workload")
+    ap.add_argument("--streamed-steps", type=int, default=3,
+                    help="timed steps of the streamed (host -> device, PCIe-inclusive) leg; 0 = skip it")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N > 1 with strong scaling: skip the secondary weak-scaling measurement")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
-def cpu_baseline(items, out_ty_name, budget_s):
+def job_items(workload, scaling, world):
+    """The job's tensor table [(name, ggml type, elements)] and its label."""
+    from gguf_amd import synth
+    base = synth.workload(workload)
+    sets = world if scaling == "weak" else 1
+    items = [(f"set{r}.{n}" if sets > 1 else n, ty, ne) for r in range(sets) for (n, ty, ne) in base]
+    label = workload if sets == 1 else f"{sets} x {workload}"
+    return base, items, label
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline
+# --------------------------------------------------------------------------------------
+def _native_oracle():
+    """The oracle rebuilt on THIS machine with -march=native (the shipped library is built
+    elsewhere for a generic x86-64).  Returns (ctypes lib or None, note)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "ggq_oracle.c")
+    try:
+        d = tempfile.mkdtemp(prefix="ggq_oracle_native_")
+        so = os.path.join(d, "libggq_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-fPIC", "-pthread", "-shared", "-o", so, src, "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        L = ctypes.CDLL(so)
+        L.ggo_dequantize_slice_mt.restype = ctypes.c_int
+        L.ggo_dequantize_slice_mt.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        return L, "-O3 -march=native"
+    except Exception as e:      # no compiler on the box, or the build failed: time the shipped build
+        return None, f"-O3 generic x86-64 (native rebuild unavailable: {type(e).__name__})"
+
+
+def cpu_baseline(items, out_ty_name, budget_s, min_elems=1_000_000_000):
     """Oracle (C port of the reference decode, blocks split over a thread pool like the
-    reference's rayon loop) on a bounded sample: the leading tensors of the workload up
-    to ~0.4 G elements, decoded repeatedly for about `budget_s` seconds; best pass."""
+    reference's rayon loop) on a bounded sample: the leading tensors of the workload up to
+    `min_elems` elements, every byte of input drawn at random (no repeated chunk, so the reads
+    come from DRAM as they would from a file mapping); median of up to 10 passes within about
+    `budget_s` seconds.  Two outputs: a pre-faulted buffer, and -- what the reference's caller
+    does (cast.rs:159-161) -- a fresh anonymous mapping per tensor."""
+    import mmap
     import numpy as np
     import oracle as o
-    from gguf_amd import synth
     from gguf_amd.quants import block_bytes, block_elems
+    from gguf_amd.synth import HEADER_F16
     o.build()
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     cores = max(1, min(cores, len(os.sched_getaffinity(0))))
@@ -66,54 +118,225 @@ def cpu_baseline(items, out_ty_name, budget_s):
     for name, ty, n in items:
         sample.append((name, ty, n))
         elems += n
-        if elems >= 400_000_000:
+        if elems >= min_elems:
             break
+    native, flags = _native_oracle()
+    rng = np.random.default_rng(0xC0FFEE04)
     bufs = []
-    for i, (name, ty, n) in enumerate(sample):
+    for name, ty, n in sample:
         blocks = n // block_elems(ty)
-        # payload content does not change the decode's cost; tile a 4 MiB random chunk
-        chunk = synth.random_blocks(ty, min(blocks, (4 << 20) // block_bytes(ty)), 0xC0FFEE04 + i)
-        reps = -(-blocks * block_bytes(ty) // chunk.size)
-        packed = np.tile(chunk, reps)[: blocks * block_bytes(ty)]
-        dst = np.zeros(n, dtype=np.float32 if ob == 4 else np.uint16)   # pre-faulted
+        bb = block_bytes(ty)
+        packed = rng.integers(0, 256, size=blocks * bb, dtype=np.uint8)
+        view = packed.reshape(blocks, bb)
+        for off in HEADER_F16.get(ty, ()):                  # finite, normal scales
+            view[:, off] = rng.integers(0, 256, size=blocks, dtype=np.uint8)
+            view[:, off + 1] = rng.integers(0x20, 0x30, size=blocks, dtype=np.uint8)
+        dst = np.empty(n, dtype=np.float32 if ob == 4 else np.uint16)
+        dst.fill(0)                                          # pre-faulted
         bufs.append((int(ty), packed, dst, blocks))
-    best = float("inf")
-    passes = 0
+
+    def decode(ty, dst, packed, blocks):
+        if native is not None:
+            st = native.ggo_dequantize_slice_mt(ty, out_ty, dst.ctypes.data, dst.size, packed.ctypes.data, blocks, cores)
+        else:
+            st = o.dequantize_status(ty, out_ty, dst, dst.size, packed, blocks, threads=cores)
+        assert st == 0
+
+    if native is not None:
+        # the native build must give the shipped build's bits before it may stand in for it
+        for ty, packed, dst, blocks in bufs[:4]:
+            nb = min(blocks, 4096)
+            a = np.empty(nb * block_elems(ty), dtype=dst.dtype)
+            b = np.empty_like(a)
+            native.ggo_dequantize_slice_mt(ty, out_ty, a.ctypes.data, a.size, packed.ctypes.data, nb, 1)
+            o.dequantize_status(ty, out_ty, b, b.size, packed, nb)
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "native oracle build differs from the shipped one"
+
+    times = []
     t_end = time.perf_counter() + budget_s
-    while passes < 2 or (time.perf_counter() < t_end and passes < 20):
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 10):
         t0 = time.perf_counter()
         for ty, packed, dst, blocks in bufs:
-            st = o.dequantize_status(ty, out_ty, dst, dst.size, packed, blocks, threads=cores)
-            assert st == 0
-        best = min(best, time.perf_counter() - t0)
-        passes += 1
-    # what the reference's caller does (cast.rs:159-161): a fresh anonymous mapping per tensor,
-    # so the decode also pays the first-touch page faults of its output
-    import mmap
-    t0 = time.perf_counter()
-    for ty, packed, dst, blocks in bufs:
-        m = mmap.mmap(-1, dst.nbytes)
-        fresh = np.frombuffer(m, dtype=dst.dtype)
-        st = o.dequantize_status(ty, out_ty, fresh, fresh.size, packed, blocks, threads=cores)
-        assert st == 0
-        del fresh
-        m.close()
-    fresh_s = time.perf_counter() - t0
-    types = sorted({o_ty for o_ty, _, _, _ in bufs})
+            decode(ty, dst, packed, blocks)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    fresh = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for ty, packed, dst, blocks in bufs:
+            m = mmap.mmap(-1, dst.nbytes)
+            f = np.frombuffer(m, dtype=dst.dtype)
+            decode(ty, f, packed, blocks)
+            del f
+            m.close()
+        fresh.append(time.perf_counter() - t0)
+    fresh_s = statistics.median(fresh)
+    types = sorted({ty for ty, _, _, _ in bufs})
     return {
-        "value": round(elems * ob / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-        "melem_per_s": round(elems / best / 1e6, 1),
+        "value": round(elems * ob / med / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+        "melem_per_s": round(elems / med / 1e6, 1),
+        "best_value": round(elems * ob / min(times) / 1e9, 3),
         "fresh_mapping_value": round(elems * ob / fresh_s / 1e9, 3),
-        "sample": f"first {len(sample)} tensors of the workload ({elems} elements, ggml types {types}), "
-                  f"pre-faulted output, best of {passes} passes",
+        "build": flags,
+        "sample": f"first {len(sample)} tensors of the workload ({elems} elements, ggml types {types}), random "
+                  f"non-repeating input, pre-faulted output, median of {len(times)} passes; fresh_mapping_value: "
+                  f"output in a fresh anonymous mapping per tensor, median of {len(fresh)} passes",
     }
+
+
+# --------------------------------------------------------------------------------------
+# GPU legs
+# --------------------------------------------------------------------------------------
+class Share:
+    """One rank's pieces of the job: packed blocks and decoded output resident in HBM, one launch
+    plan per block type (largest first)."""
+
+    def __init__(self, pieces, out_name, dev, seed_base):
+        import torch
+        import gguf_amd as g
+        from gguf_amd import synth
+        from gguf_amd.quants import GGmlType, block_bytes
+        self.out_name = out_name
+        self.ob = 4 if out_name == "f32" else 2
+        out_dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out_name]
+        self.out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out_name]
+        self.pieces = pieces
+        self.elems = sum(p.elems for p in pieces)
+        self.packed_bytes = sum(p.blocks * block_bytes(p.ggml_type) for p in pieces)
+        need = self.elems * self.ob + self.packed_bytes
+        free = torch.cuda.mem_get_info(dev)[0]
+        if need > 0.97 * free:
+            raise MemoryError(f"this share needs {need / 2**30:.1f} GiB of HBM, {free / 2**30:.1f} GiB are free; "
+                              f"use more GPUs (strong scaling) or --out f16")
+        self.dst_all = torch.empty(self.elems, dtype=out_dt, device=dev)
+        self.by_type = {}
+        at = 0
+        for i, p in enumerate(pieces):
+            src = synth.random_blocks_device(p.ggml_type, p.blocks, seed_base + i, dev)
+            dst = self.dst_all[at:at + p.elems]
+            at += p.elems
+            self.by_type.setdefault(int(p.ggml_type), []).append((p.ggml_type, src, dst))
+        self.order = sorted(self.by_type, key=lambda t: -sum(x[2].numel() for x in self.by_type[t]))
+        self.plans = [(ty, g.Batch(self.by_type[ty], self.out_ty)) for ty in self.order]
+        self.launches = sum(b.launches for _, b in self.plans)
+
+    def step(self, stream):
+        for _, b in self.plans:
+            b.run(stream)
+
+    def poison(self):
+        import torch
+        if self.ob == 2:
+            self.dst_all.view(torch.int16).fill_(0x7FC1)
+        else:
+            self.dst_all.view(torch.int32).fill_(0x7FC00001)
+
+    def verify(self, seed):
+        """Random blocks of every launch plan and their outputs against the CPU oracle, bit for
+        bit (a NaN matches any NaN).  Returns (blocks checked, ok)."""
+        import numpy as np
+        import oracle as o
+        from gguf_amd import synth
+        o.build()
+        o_out = {"f32": o.F32, "f16": o.F16, "bf16": o.BF16}[self.out_name]
+        checked, ok = 0, True
+        for ty in self.order:
+            packed, got = synth.sample_blocks(self.by_type[ty], VERIFY_BLOCKS, seed + ty)
+            want = o.dequantize(ty, packed, o_out, threads=8)
+            if self.ob == 4:
+                same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            else:
+                same = got == want        # benign blocks give no NaN
+            ok = ok and bool(same.all())
+            checked += VERIFY_BLOCKS
+        return checked, ok
+
+    def close(self):
+        for _, b in self.plans:
+            b.close()
+        self.plans = []
+
+
+def timed_resident(share, steps, warmup, settle_ms, fence, with_events=True):
+    """W warm-up steps, then exactly `steps` timed steps between fences.  Returns (seconds on this
+    rank, per-plan average launch ms or None)."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    # The GPU reaches its steady clocks only after some tens of milliseconds of load (measured:
+    # the same launch runs 9 % slower in the first few milliseconds after an idle period), so
+    # untimed steps run until `settle_ms` of wall time have passed, then the W warm-up steps.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+        share.step(stream)
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        share.step(stream)
+    fence()
+    # HIP events on the launch stream around every kernel, inside the timed region.  An event
+    # between two launches costs the GPU a few microseconds of idle time (measured: 2 % of a
+    # 4.7 ms step, 10 % of a 0.85 ms one), so only every `every`-th step carries them; the
+    # kernel durations reported are the averages over those steps.
+    every = max(1, steps // 5)
+    sampled = [s for s in range(steps) if s % every == 0] if with_events else []
+    nplans = len(share.plans)
+    ev = {s: [torch.cuda.Event(enable_timing=True) for _ in range(nplans + 1)] for s in sampled}
+    t0 = time.perf_counter()
+    for s in range(steps):
+        if s in ev:
+            ev[s][0].record()
+            for k, (_, b) in enumerate(share.plans):
+                b.run(stream)
+                ev[s][k + 1].record()
+        else:
+            share.step(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = None
+    if sampled:
+        kern_ms = [sum(ev[s][k].elapsed_time(ev[s][k + 1]) for s in sampled) / len(sampled) for k in range(nplans)]
+    return elapsed, kern_ms, len(sampled)
+
+
+def streamed_leg(share, local, steps, fence, max_over_ranks):
+    """The same share decoded from page-locked host memory: every piece goes through
+    ggq_dequantize_async (chunked H2D copy and decode kernel overlapping on the context's two
+    streams), the decoded tensors stay in HBM.  One step = the whole share once."""
+    import torch
+    import gguf_amd as g
+    staging = 128 << 20
+    arena = torch.empty(share.packed_bytes, dtype=torch.uint8, pin_memory=True)
+    work, at = [], 0
+    for ty in share.order:
+        for (t, src, dst) in share.by_type[ty]:
+            n = src.numel()
+            arena[at:at + n].copy_(src)
+            work.append((t, dst, arena[at:at + n]))
+            at += n
+    torch.cuda.synchronize()
+    ctx = g.Context(local, staging_bytes=staging)
+
+    def step():
+        for t, dst, h in work:
+            ctx.dequantize_async(t, dst, h)
+        ctx.sync()
+
+    share.poison()
+    step()                                  # warm-up (also the pass that gets verified)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    ctx.close()
+    return elapsed, staging
 
 
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    import gguf_amd as g
+    import gguf_amd as g  # noqa: F401
     from gguf_amd import shard, synth
     from gguf_amd.quants import GGmlType, block_bytes, block_elems
 
@@ -127,52 +350,16 @@ def main():
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     ndev = torch.cuda.device_count()
-    # Normal case: one rank per GPU over RCCL.  Rehearsal case (fewer GPUs than ranks,
-    # e.g. two ranks on a one-GPU box): ranks share devices and the process group is gloo
-    # on host tensors -- the group only carries the barriers and the max of the times.
+    # Normal case: one rank per GPU.  Rehearsal case (fewer GPUs than ranks, e.g. two ranks on a
+    # one-GPU box): ranks share devices.  Either way the process group is gloo on host tensors: it
+    # carries nothing but barriers and the max of the times, the data path has no exchange step.
     shared = world > ndev
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    # ---- the job: `world` tensor sets, dealt to ranks by the index partition -------
-    base = synth.workload(args.workload)
-    sets = world if args.scaling == "weak" else 1
-    items = [(f"set{r}.{n}", ty, ne) for r in range(sets) for (n, ty, ne) in base]
-    mine = shard.partition(items, world)[rank]
-    out_dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.out]
-    ob = 4 if args.out == "f32" else 2
-    out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[args.out]
-
-    my_elems = sum(p.elems for p in mine)
-    need = my_elems * ob + sum(p.blocks * block_bytes(p.ggml_type) for p in mine)
-    free = torch.cuda.mem_get_info(dev)[0]
-    if need > 0.97 * free:
-        sys.exit(f"rank {rank}: this share needs {need / 2**30:.1f} GiB of HBM, {free / 2**30:.1f} GiB are free; "
-                 f"use more GPUs with --scaling strong, or --out f16")
-    dst_all = torch.empty(my_elems, dtype=out_dt, device=dev)
-    by_type = {}
-    at = 0
-    for i, p in enumerate(mine):
-        src = synth.random_blocks_device(p.ggml_type, p.blocks, 0xC0FFEE04 + 1000 * rank + i, dev)
-        dst = dst_all[at:at + p.elems]
-        at += p.elems
-        by_type.setdefault(p.ggml_type, []).append((p.ggml_type, src, dst))
-    # one launch plan per block type, so each kernel can be timed on its own
-    order = sorted(by_type, key=lambda t: -sum(x[2].numel() for x in by_type[t]))
-    plans = [(ty, g.Batch(by_type[ty], out_ty)) for ty in order]
-    launches = sum(b.launches for _, b in plans)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        for _, b in plans:
-            b.run(stream)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def fence():
         torch.cuda.synchronize()
@@ -180,95 +367,155 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The GPU reaches its steady clocks only after some tens of milliseconds of load (measured:
-    # the same launch runs 9 % slower in the first few milliseconds after an idle period), so
-    # untimed steps run until `settle_ms` of wall time have passed, then the W warm-up steps.
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-        step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # HIP events on the launch stream around every kernel, inside the timed region.  An event
-    # between two launches costs the GPU a few microseconds of idle time (measured: 2 % of a
-    # 4.7 ms step, 10 % of a 0.85 ms one), so only every `every`-th step carries them; the
-    # kernel durations reported are the averages over those steps.
-    every = max(1, args.steps // 5)
-    sampled = [s for s in range(args.steps) if s % every == 0]
-    ev = {s: [torch.cuda.Event(enable_timing=True) for _ in range(len(plans) + 1)] for s in sampled}
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        if s in ev:
-            ev[s][0].record()
-            for k, (_, b) in enumerate(plans):
-                b.run(stream)
-                ev[s][k + 1].record()
-        else:
-            for _, b in plans:
-                b.run(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # per-kernel launch durations (ms), averaged over the timed steps
-    kern_ms = []
-    for k in range(len(plans)):
-        kern_ms.append(sum(ev[s][k].elapsed_time(ev[s][k + 1]) for s in sampled) / len(sampled))
+    def all_ok(blocks, ok):
+        if world == 1:
+            return blocks, ok
+        t = torch.tensor([blocks, 0 if ok else 1], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t[0]), int(t[1]) == 0
 
+    # ---- the job, dealt to ranks by the index partition -----------------------------
+    base, items, label = job_items(args.workload, args.scaling, world)
+    shares = shard.partition(items, world, out_bytes=4 if args.out == "f32" else 2)
+    try:
+        share = Share(shares[rank], args.out, dev, 0xC0FFEE04 + 100000 * rank)
+    except MemoryError as e:
+        sys.exit(f"rank {rank}: {e}")
+    ob = share.ob
+
+    elapsed, kern_ms, timed_launches = timed_resident(share, args.steps, args.warmup, args.settle_ms, fence)
+    elapsed = max_over_ranks(elapsed)
+
+    verified = None
+    if not args.no_verify:
+        share.poison()
+        share.step(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        blocks, ok = share.verify(4242 + rank)
+        blocks, ok = all_ok(blocks, ok)
+        verified = {"blocks": blocks, "ok": ok, "how": f"{VERIFY_BLOCKS} random blocks per launch plan and rank, "
+                    "outputs of one more (untimed) step after the timed region, bit for bit against the CPU oracle"}
+
+    streamed = None
+    if args.streamed_steps > 0:
+        try:
+            s_elapsed, staging = streamed_leg(share, local, args.streamed_steps, fence, max_over_ranks)
+            s_blocks, s_ok = (0, True) if args.no_verify else share.verify(777 + rank)
+            s_blocks, s_ok = all_ok(s_blocks, s_ok)
+            pin, pout, nel = synth.workload_bytes(items, ob)
+            per = s_elapsed / args.streamed_steps
+            streamed = {
+                "steps": args.streamed_steps, "ms_per_step": round(per * 1e3, 3),
+                "end_to_end_GBps": round(pout / per / 1e9, 2), "packed_pcie_GBps": round(pin / per / 1e9, 2),
+                "packed_pcie_GBps_per_gpu": round(pin / per / 1e9 / world, 2),
+                "melem_per_s": round(nel / per / 1e6, 1), "bound": "pcie (H2D)",
+                "path": "ggq_dequantize_async per tensor piece: page-locked host source read in place, "
+                        f"{staging >> 20} MiB device staging in 2 slots, copy and decode on 2 streams; decoded tensors stay in HBM",
+                "verified": None if args.no_verify else {"blocks": s_blocks, "ok": s_ok},
+            }
+        except Exception as e:          # never lose the main line to the secondary leg
+            streamed = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            dist.barrier()
+
+    order = share.order
+    dom_elems_by_type = {ty: sum(x[2].numel() for x in share.by_type[ty]) for ty in share.order}
+    launches = share.launches
+
+    # secondary: weak scaling (every rank one whole set), when the headline is strong scaling
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_secondary:
+        try:
+            share.close()
+            share = None
+            torch.cuda.empty_cache()
+            _, w_items, w_label = job_items(args.workload, "weak", world)
+            w_share = Share(shard.partition(w_items, world, out_bytes=ob)[rank], args.out, dev,
+                            0xC0FFEE04 + 100000 * rank)
+            w_elapsed, _, _ = timed_resident(w_share, args.steps, args.warmup, args.settle_ms, fence, with_events=False)
+            w_elapsed = max_over_ranks(w_elapsed)
+            _, w_pout, w_nel = synth.workload_bytes(w_items, ob)
+            weak = {"scaling": "weak", "workload": w_label, "value": round(w_pout / (w_elapsed / args.steps) / 1e9, 2),
+                    "unit": "GB/s", "ms_per_step": round(w_elapsed / args.steps * 1e3, 4),
+                    "melem_per_s": round(w_nel / (w_elapsed / args.steps) / 1e6, 1)}
+            w_share.close()
+            del w_share
+        except Exception as e:
+            weak = {"error": f"{type(e).__name__}: {e}"}
+
+    rc = 0
     if rank == 0:
         total_elems = sum(ne for _, _, ne in items)
         pin, pout, _ = synth.workload_bytes(items, ob)
-        ms = elapsed / args.steps * 1e3
+        per = elapsed / args.steps
         dom_ty = order[0]
-        dom_elems = sum(x[2].numel() for x in by_type[dom_ty])
+        dom_elems = dom_elems_by_type[dom_ty]
         per_elem = block_bytes(dom_ty) / block_elems(dom_ty) + ob
         dom_bytes = dom_elems * per_elem
         achieved = dom_bytes / (kern_ms[0] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_path):
+        if world == 1 and os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 key = f"{args.workload}:{args.out}:{GGmlType(dom_ty).name}"
-                traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
+                if key in tr:
+                    traffic = tr[key].get("hbm_bytes_per_launch")
+                    traffic_source = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch recorded in "
+                                      f"profiles/traffic.json ({tr[key].get('round', 'r01')}), not measured in this run")
             except Exception:
                 traffic = None
         rec = {
-            "metric": "dequantized_GBps", "value": round(pout / (elapsed / args.steps) / 1e9, 2), "unit": "GB/s",
+            "metric": "dequantized_GBps", "value": round(pout / per / 1e9, 2), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
-            "ms_per_step": round(ms, 4),
+            "ms_per_step": round(per * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "io": "u8->" + args.out, "data": "synthetic",
-            "config": {"workload": (args.workload if sets == 1 else f"{sets} x {args.workload}")
-                       + (f" (REHEARSAL: {world} ranks share {ndev} GPU)" if shared else ""),
+            "config": {"workload": label + (f" (REHEARSAL: {world} ranks share {ndev} GPU)" if shared else ""),
                        "tensors": len(items), "elements": total_elems, "packed_bytes": pin,
                        "decoded_bytes": pout, "partition": "index (LPT), no collective",
                        "kernel_launches_per_step": launches},
-            "melem_per_s": round(total_elems / (elapsed / args.steps) / 1e6, 1),
-            "packed_GBps": round(pin / (elapsed / args.steps) / 1e9, 2),
-            "algorithmic_GBps": round((pin + pout) / (elapsed / args.steps) / 1e9, 2),
-            "kernels": [{"type": GGmlType(ty).name, "elements": sum(x[2].numel() for x in by_type[ty]),
+            "melem_per_s": round(total_elems / per / 1e6, 1),
+            "packed_GBps": round(pin / per / 1e9, 2),
+            "algorithmic_GBps": round((pin + pout) / per / 1e9, 2),
+            "kernels": [{"type": GGmlType(ty).name, "elements": dom_elems_by_type[ty],
                          "avg_ms": round(kern_ms[k], 4)} for k, ty in enumerate(order)],
             "roofline": {"bound": "hbm", "kernel": f"deq_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(kern_ms[0], 4),
-                         "timed_launches": len(sampled)},
+                         "timed_launches": timed_launches},
         }
+        if verified is not None:
+            rec["verified"] = verified
+            if not verified["ok"]:
+                rc = 1
+        if streamed is not None:
+            rec["streamed"] = streamed
+            if streamed.get("verified") and not streamed["verified"]["ok"]:
+                rc = 1
+        if weak is not None:
+            rec["secondary"] = weak
         if world == 1 and not args.no_cpu_baseline:
-            for _, b in plans:
-                b.close()
-            del dst_all, by_type, plans
+            if share is not None:
+                share.close()
+                share = None
             torch.cuda.empty_cache()
             rec["cpu_baseline"] = cpu_baseline(base, args.out, args.cpu_seconds)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit("bench.py: the outputs of the timed kernels differ from the CPU oracle")
 
 
 if __name__ == "__main__":
