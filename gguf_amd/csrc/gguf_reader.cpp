@@ -214,19 +214,37 @@ ggq_gguf_error parse_into(ggq_gguf *g) {
         t.ndim = r.read<uint32_t>();
         if (r.err) return r.err;
         if ((uint64_t)t.ndim > r.left / 8) return GGQ_GGUF_EOS;
+        // ggml tensors have at most 4 dimensions, and the C view of a tensor holds 4
+        if (t.ndim > 4) { g_name = std::string(t.name); return GGQ_GGUF_TENSOR_RANGE; }
         uint64_t others = 1, first = 1;
+        bool wraps = false;
         for (uint32_t d = 0; d < t.ndim; ++d) {
             uint64_t s = r.read<uint64_t>();
-            if (d < 4) t.shape[d] = s;
-            if (d == 0) first = s; else others *= s;
+            t.shape[d] = s;
+            if (d == 0) first = s;
+            else wraps |= __builtin_mul_overflow(others, s, &others);
         }
         t.ty = r.read<uint32_t>();
         t.offset = r.read<uint64_t>();
         if (r.err) return r.err;
-        // GGmlTypeSize::elements_to_bytes (tensor.rs:83-96)
+        // GGmlTypeSize::elements_to_bytes (tensor.rs:83-96).  The numbers come from the file:
+        // where the reference asserts (shape[0] % block) or its arithmetic would wrap, the
+        // parse fails instead of handing out geometry that does not match the bytes.
         const TypeSize *ts = file_type(t.ty);
-        if (ts) t.nbytes = t.ndim == 0 ? ts->bytes : others * first / ts->elems * ts->bytes;
-        data_len = std::max(data_len, t.offset + t.nbytes);
+        if (!ts) { g_name = std::string(t.name); return GGQ_GGUF_INDIVISIBLE; }
+        if (t.ndim == 0) {
+            if (ts->elems != 1) { g_name = std::string(t.name); return GGQ_GGUF_INDIVISIBLE; }
+            t.nbytes = ts->bytes;
+        } else {
+            if (first % ts->elems != 0) { g_name = std::string(t.name); return GGQ_GGUF_INDIVISIBLE; }
+            uint64_t blocks = 0;
+            wraps |= __builtin_mul_overflow(others, first / ts->elems, &blocks);
+            wraps |= __builtin_mul_overflow(blocks, (uint64_t)ts->bytes, &t.nbytes);
+        }
+        uint64_t end = 0;
+        wraps |= __builtin_add_overflow(t.offset, t.nbytes, &end);
+        if (wraps) { g_name = std::string(t.name); return GGQ_GGUF_TENSOR_RANGE; }
+        data_len = std::max(data_len, end);
         if (!g->tensor_index.emplace(t.name, g->tensors.size()).second) { g_name = std::string(t.name); return GGQ_GGUF_DUP_TENSOR; }
         g->tensors.push_back(t);
     }
@@ -248,7 +266,8 @@ void fill_tensor(const ggq_gguf *g, const Tensor &t, ggq_gguf_tensor *out) {
     std::memcpy(out->shape, t.shape, sizeof t.shape);
     out->offset = t.offset;
     out->nbytes = t.nbytes;
-    const bool held = t.nbytes > 0 && t.offset + t.nbytes <= g->info.data_avail;
+    // offset + nbytes cannot wrap: parse_into refused such tensors
+    const bool held = t.nbytes > 0 && t.offset <= g->info.data_avail && t.nbytes <= g->info.data_avail - t.offset;
     out->data = held ? g->base + g->info.data_offset + t.offset : nullptr;
 }
 
@@ -280,8 +299,9 @@ ggq_gguf_error ggq_gguf_open(const char *path, ggq_gguf **out) {
     if (!out || !path) return GGQ_GGUF_INVALID;
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) return GGQ_GGUF_IO;
-    struct stat st;
-    if (::fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return st.st_size == 0 ? GGQ_GGUF_EOS : GGQ_GGUF_IO; }
+    struct stat st{};
+    if (::fstat(fd, &st) != 0) { ::close(fd); return GGQ_GGUF_IO; }
+    if (st.st_size <= 0) { ::close(fd); return st.st_size == 0 ? GGQ_GGUF_EOS : GGQ_GGUF_IO; }
     void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (m == MAP_FAILED) return GGQ_GGUF_IO;
@@ -322,6 +342,7 @@ const char *ggq_gguf_error_str(ggq_gguf_error e) {
     case GGQ_GGUF_NOT_FOUND: return "not found";
     case GGQ_GGUF_INVALID: return "invalid argument";
     case GGQ_GGUF_INDIVISIBLE: return "shape is not a whole number of blocks of the type";
+    case GGQ_GGUF_TENSOR_RANGE: return "tensor geometry out of range (more than 4 dimensions, or sizes that overflow 64 bits)";
     }
     return "unknown error";
 }

@@ -16,7 +16,7 @@ from .quants import GGmlType, block_bytes, block_elems
 OK = 0
 ERRORS = {1: "Eos", 2: "Utf8", 3: "Bool", 4: "MagicMismatch", 5: "EndianNotSupport", 6: "VersionNotSupport",
           7: "AlignmentTypeMismatch", 8: "DuplicateMetaKey", 9: "DuplicateTensorName", 10: "Io",
-          11: "ValueType", 12: "NotFound", 13: "Invalid", 14: "Indivisible"}
+          11: "ValueType", 12: "NotFound", 13: "Invalid", 14: "Indivisible", 15: "TensorRange"}
 DEFAULT_ALIGNMENT = 32
 
 _SCALAR = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 6: "<f", 7: "<?", 10: "<Q", 11: "<q", 12: "<d"}
@@ -34,7 +34,7 @@ class GGufError(Exception):
 
 def _check(code):
     if code != OK:
-        name = lib.ggq_gguf_last_name().decode() if code in (7, 8, 9) else ""
+        name = lib.ggq_gguf_last_name().decode() if code in (7, 8, 9, 14, 15) else ""
         raise GGufError(code, name)
 
 

@@ -44,8 +44,11 @@ typedef enum ggq_gguf_error {
     GGQ_GGUF_VALUE_TYPE = 11,      /* unknown metadata value type id                      */
     GGQ_GGUF_NOT_FOUND = 12,       /* no such key / tensor / index                        */
     GGQ_GGUF_INVALID = 13,         /* null argument / call out of order                   */
-    GGQ_GGUF_INDIVISIBLE = 14      /* shape[0] is not a whole number of blocks (the reference asserts,
+    GGQ_GGUF_INDIVISIBLE = 14,     /* shape[0] is not a whole number of blocks (the reference asserts,
                                       ggus/src/tensor.rs:83-96), or the type has no known size */
+    GGQ_GGUF_TENSOR_RANGE = 15     /* a tensor has more than 4 dimensions, or its shape product, byte size
+                                      or offset + size wraps 64 bits (the reference's checked arithmetic
+                                      panics, ggus/src/file.rs:104-106)                                  */
 } ggq_gguf_error;
 
 /* GGufMetaDataValueType (ggus/src/metadata/mod.rs) */

@@ -238,4 +238,46 @@ def test_hostile_headers(blob):
             for t in g.tensors:
                 assert t.ptr is None        # nothing of these can be backed by the buffer
     except G.GGufError as e:
-        assert e.kind in ("Eos", "ValueType", "Invalid")
+        assert e.kind in ("Eos", "ValueType", "Invalid", "TensorRange", "Indivisible")
+
+
+def _with_data(tensor_meta, data_bytes=4096):
+    """One tensor record followed by padding to 32 and a NON-EMPTY data region."""
+    head = _hdr(1, 0) + tensor_meta
+    head += b"\0" * ((32 - len(head) % 32) % 32)
+    return np.frombuffer(head + bytes(range(256)) * (data_bytes // 256), dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("meta,kind", [
+    # offset + nbytes wraps to a small number: F16 [32] = 64 bytes at offset 2^64 - 63
+    (_s(b"t") + struct.pack("<IQIQ", 1, 32, 1, 2 ** 64 - 63), "TensorRange"),
+    (_s(b"t") + struct.pack("<IQIQ", 1, 32, 1, 2 ** 64 - 64), "TensorRange"),
+    # shape product wraps: 2^33 x 2^33 F32 -> 2^66 elements
+    (_s(b"t") + struct.pack("<IQQIQ", 2, 2 ** 33, 2 ** 33, 0, 0), "TensorRange"),
+    # product fits, bytes wrap: 2^62 F32 elements -> 2^64 bytes
+    (_s(b"t") + struct.pack("<IQQIQ", 2, 2 ** 31, 2 ** 31, 0, 0), "TensorRange"),
+    # three dimensions whose running product wraps back to a small value: 2^32 * 2^32 * 1
+    (_s(b"t") + struct.pack("<IQQQIQ", 3, 256, 2 ** 32, 2 ** 32, 12, 0), "TensorRange"),
+    # five dimensions
+    (_s(b"t") + struct.pack("<IQQQQQIQ", 5, 2, 2, 2, 2, 2, 0, 0), "TensorRange"),
+    # shape[0] not a whole number of blocks (Q4_K wants multiples of 256); unknown type id; scalar of a block type
+    (_s(b"t") + struct.pack("<IQQIQ", 2, 100, 4, 12, 0), "Indivisible"),
+    (_s(b"t") + struct.pack("<IQIQ", 1, 32, 77, 0), "Indivisible"),
+    (_s(b"t") + struct.pack("<IIQ", 0, 12, 0), "Indivisible"),
+])
+def test_hostile_tensor_geometry_with_data_present(meta, kind):
+    """With a data region present, geometry that wraps 64 bits must not turn into a pointer: the reference's
+    checked arithmetic panics here, the parser answers with an error."""
+    with pytest.raises(G.GGufError) as e:
+        G.GGuf.from_bytes(_with_data(meta))
+    assert e.value.kind == kind and e.value.name == "t"
+
+
+def test_offset_beyond_data_is_not_backed():
+    """In range arithmetically but beyond the bytes present: parsed, ptr is None (metadata-only files)."""
+    buf = _with_data(_s(b"t") + struct.pack("<IQIQ", 1, 32, 1, 4096 - 63))      # 64 bytes, 1 byte short
+    with G.GGuf.from_bytes(buf) as g:
+        assert g.tensors[0].ptr is None
+    buf = _with_data(_s(b"t") + struct.pack("<IQIQ", 1, 32, 1, 4096 - 64))      # exactly fits
+    with G.GGuf.from_bytes(buf) as g:
+        assert g.tensors[0].ptr is not None and bytes(g.tensors[0].bytes()[-1:]) == b"\xff"
