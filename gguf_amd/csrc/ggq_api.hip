@@ -138,8 +138,19 @@ HostGeom host_geom(const TypeInfo *ti, uint32_t out_ty) {
     uint64_t elems = (uint64_t)WG_THREADS * epl * STORES_PER_THREAD;
     return {elems, elems / ti->elems, elems / ti->elems * ti->bytes};
 }
-// gridDim.x limit kept well below 2^31; larger tensors take several launches
-constexpr uint64_t kMaxGrid = 1u << 30;
+// Workgroups per launch.  A dispatch's total work-item count (grid x 512) must fit 32 bits, so a
+// launch carries at most 2^22 workgroups (4 Mi tiles = 16 Gi f32 elements); larger tensors or batch
+// groups take several launches.  GGQ_MAX_GRID (environment, read once) lowers the limit so that tests
+// can drive the multi-launch path with small inputs.
+const uint64_t kMaxGrid = [] {
+    uint64_t lim = ((1ull << 32) - 1) / WG_THREADS;
+    lim = 1ull << 22 < lim ? 1ull << 22 : lim;
+    if (const char *e = std::getenv("GGQ_MAX_GRID")) {
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v >= 1 && v < lim) lim = v;
+    }
+    return lim;
+}();
 
 #define GGQ_FORMATS(X)                                                                      \
     X(GGQ_TYPE_Q4_0, Q4_0) X(GGQ_TYPE_Q4_1, Q4_1) X(GGQ_TYPE_Q5_0, Q5_0) X(GGQ_TYPE_Q5_1, Q5_1) \
@@ -371,7 +382,7 @@ class CopyPool {
     std::condition_variable cv;
     std::deque<Task> q;
     int helpers = 0;
-    bool started = false;
+    std::once_flag once;
 
     void work() {
         for (;;) {
@@ -387,9 +398,6 @@ class CopyPool {
         }
     }
     void start() {
-        std::lock_guard<std::mutex> lk(m);
-        if (started) return;
-        started = true;
         const char *e = std::getenv("GGQ_COPY_THREADS");
         int n = e ? std::atoi(e) : 3;
         n = std::max(0, std::min(n, 15));
@@ -406,7 +414,7 @@ class CopyPool {
 public:
     void copy(void *dst, const void *src, size_t n) {
         constexpr size_t kMinSlice = 1u << 20;
-        if (!started) start();
+        std::call_once(once, [this] { start(); });   // helpers is final (and visible) after this
         const size_t parts = std::min<size_t>((size_t)helpers + 1, n / kMinSlice);
         if (parts <= 1) {
             memcpy(dst, src, n);
@@ -481,11 +489,11 @@ ggq_status ctx_make(int device, size_t in_cap, size_t out_cap, ggq_ctx **out) {
     HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(device));
     ggq_ctx *c = new (std::nothrow) ggq_ctx();
-    if (!c) return GGQ_INVALID;
+    if (!c) { (void)hipSetDevice(prev); return GGQ_INVALID; }
     c->device = device;
     DevInfo di;
     ggq_status st = dev_info(device, di);
-    if (st != GGQ_OK) { delete c; return st; }
+    if (st != GGQ_OK) { delete c; (void)hipSetDevice(prev); return st; }
     c->cus = di.cus;
     c->in_cap = in_cap;
     c->out_cap = out_cap;
@@ -836,14 +844,17 @@ ggq_status ggq_permute_qk_device(uint32_t ty, uint64_t row_elems, uint64_t rows,
     const uint64_t pieces = rb / vec * rows;
     const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
     const uint64_t wgs = (pieces + per_wg - 1) / per_wg;
-    if (wgs > kMaxGrid) return GGQ_INVALID;
     hipStream_t q = (hipStream_t)hip_stream;
     uint8_t *o = (uint8_t *)d_dst;
     const uint8_t *i = (const uint8_t *)d_src;
-    if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
-    else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
-    else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows<2>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
-    else hipLaunchKernelGGL((permute_qk_rows<1>), dim3((uint32_t)wgs), dim3(WG_THREADS), 0, q, o, i, rb, rows, dh);
+    for (uint64_t w0 = 0; w0 < wgs; w0 += kMaxGrid) {
+        const dim3 grid((uint32_t)std::min(kMaxGrid, wgs - w0)), wg(WG_THREADS);
+        const uint64_t first = w0 * per_wg;
+        if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+        else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+        else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows<2>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+        else hipLaunchKernelGGL((permute_qk_rows<1>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+    }
     HIP_TRY(hipGetLastError());
     return GGQ_OK;
 }
@@ -914,6 +925,13 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
 
 ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
     if (!b) return GGQ_INVALID;
+    // the plan's table and tensors live on the device that was current at ggq_batch_create
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != b->device) {
+        g_err = "ggq_batch_run: the current device is not the one the batch was created on";
+        return GGQ_INVALID;
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     for (const auto &g : b->groups) {
         ggq_status rc;

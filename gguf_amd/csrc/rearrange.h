@@ -20,10 +20,12 @@ namespace ggq {
 template <uint32_t VEC>
 __global__ __launch_bounds__(WG_THREADS) void permute_qk_rows(uint8_t *__restrict__ dst,
                                                               const uint8_t *__restrict__ src,
-                                                              uint64_t row_bytes, uint64_t rows, uint64_t dh) {
+                                                              uint64_t row_bytes, uint64_t rows, uint64_t dh,
+                                                              uint64_t first) {
+    // `first`: piece index this launch starts at (a tensor beyond the grid limit takes several launches)
     const uint64_t pieces_per_row = row_bytes / VEC;
     const uint64_t total = pieces_per_row * rows;
-    const uint64_t base = (uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x;
+    const uint64_t base = first + (uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x;
 #pragma unroll
     for (uint32_t k = 0; k < STORES_PER_THREAD; ++k) {
         const uint64_t p = base + (uint64_t)k * WG_THREADS;

@@ -163,7 +163,8 @@ typedef struct ggq_batch ggq_batch;
  * device table).  The plan can be run any number of times. */
 ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t out_type,
                             ggq_batch **out);
-/* Enqueues the plan's kernels on `hip_stream`; does not synchronize. */
+/* Enqueues the plan's kernels on `hip_stream`; does not synchronize.  The device that was
+ * current at ggq_batch_create must be current again (GGQ_INVALID otherwise). */
 ggq_status ggq_batch_run(ggq_batch *batch, void *hip_stream);
 /* Kernel launches one run issues (for measurement bookkeeping). */
 size_t ggq_batch_launches(const ggq_batch *batch);
@@ -181,7 +182,10 @@ void ggq_batch_destroy(ggq_batch *batch);
  * the call returns.  d_dst is written on the context's own streams.  No counterpart
  * in the reference;
  * this is the whole-model conversion path (one context per GPU, tensors dealt
- * to GPUs by an index partition). */
+ * to GPUs by an index partition).
+ * Threading: a context belongs to ONE caller at a time -- its slots and streams are not
+ * locked; calls on the same context from several threads must be serialized by the caller.
+ * Different contexts, also on the same device, are independent and may be used concurrently. */
 typedef struct ggq_ctx ggq_ctx;
 ggq_status ggq_ctx_create(int device, size_t staging_bytes, ggq_ctx **out);
 ggq_status ggq_dequantize_async(ggq_ctx *ctx, uint32_t ggml_type, uint32_t out_type,

@@ -1,0 +1,18 @@
+"""Inputs beyond the per-launch grid limit take several kernel launches (launch_blocks, launch_batch,
+launch_quant, widen, narrow, permute).  The limit is 2^22 workgroups -- 16 Gi elements -- so the offset
+arithmetic of that path is driven here with GGQ_MAX_GRID=3 (read once at library load, hence a child
+process) on small inputs, against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_launch_paths(oracle):
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_launch_child.py")
+    env = dict(os.environ, GGQ_MAX_GRID="3")
+    r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])

@@ -568,7 +568,7 @@ int main(int argc, char **argv) {
             std::snprintf(label, sizeof label, "permute_qk rows of %llu bytes", (unsigned long long)rb);
             vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
                               hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(WG_THREADS), 0, s,
-                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh); }, {}});
+                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh, (uint64_t)0); }, {}});
         }
     }
     QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
