@@ -113,10 +113,14 @@ class Borrowed:
     def __init__(self, arr, nbytes):
         self.arr, self.nbytes = arr, nbytes
 
-    def device(self, dev):
+    def device(self, dev, up=None):
+        """`up`: host array -> uint8 device tensor (the producer's pinned, streamed upload); without one
+        the bytes go up with a plain blocking copy."""
         import torch
         if self.arr is None:
             raise ValueError("the input file holds no data for this tensor")
+        if up is not None:
+            return up(self.arr)
         return torch.from_numpy(self.arr).to(dev)
 
 
@@ -126,8 +130,14 @@ class Cast:
     def __init__(self, src, row, from_ty, to_ty, nbytes):
         self.src, self.row, self.from_ty, self.to_ty, self.nbytes = src, row, from_ty, to_ty, nbytes
 
-    def device(self, dev):
-        return cast_device(self.row, self.src.device(dev), self.from_ty, self.to_ty)
+    def device(self, dev, up=None):
+        return cast_device(self.row, self.src.device(dev, up), self.from_ty, self.to_ty)
+
+    def is_decode(self):
+        """A decode (or widening) of bytes that come straight from an input file: the casts that can share
+        one launch plan with others of their kind."""
+        return (isinstance(self.src, Borrowed) and self.to_ty in _FLOATS and self.from_ty not in (GGmlType.F32,)
+                and (self.from_ty not in _FLOATS or self.to_ty == GGmlType.F32) and block_bytes(self.from_ty) != 0)
 
 
 class Concat:
@@ -138,8 +148,8 @@ class Concat:
         self.ty, self.row_elems, self.parts = ty, row_elems, parts
         self.nbytes = sum(n.nbytes for n, _ in parts)
 
-    def device(self, dev):
-        return rearrange.concat_rows(self.ty, self.row_elems, [(n.device(dev), r) for n, r in self.parts])
+    def device(self, dev, up=None):
+        return rearrange.concat_rows(self.ty, self.row_elems, [(n.device(dev, up), r) for n, r in self.parts])
 
 
 class Slice:
@@ -149,8 +159,8 @@ class Slice:
     def __init__(self, src, start, nbytes):
         self.src, self.start, self.nbytes = src, start, nbytes
 
-    def device(self, dev):
-        return self.src.device(dev)[self.start:self.start + self.nbytes].clone()
+    def device(self, dev, up=None):
+        return self.src.device(dev, up)[self.start:self.start + self.nbytes].clone()
 
 
 class PermuteQK:
@@ -159,8 +169,8 @@ class PermuteQK:
     def __init__(self, src, ty, row_elems, rows, nh):
         self.src, self.ty, self.row_elems, self.rows, self.nh, self.nbytes = src, ty, row_elems, rows, nh, src.nbytes
 
-    def device(self, dev):
-        return rearrange.permute_qk(self.ty, self.row_elems, self.rows, self.nh, self.src.device(dev))
+    def device(self, dev, up=None):
+        return rearrange.permute_qk(self.ty, self.row_elems, self.rows, self.nh, self.src.device(dev, up))
 
 
 def _slice(src, start, nbytes):
@@ -460,14 +470,18 @@ class Content:
 
 
 class _Producer:
-    """Evaluates a shard's lazy tensors on the GPU in file order, one tensor ahead of the writer, into two
-    pinned host buffers that alternate."""
+    """Evaluates a shard's lazy tensors on the GPU in file order, ahead of the writer, into two pinned host
+    buffers that alternate.  Input bytes go up through the producer's own Context (pinned staging, read
+    from the file mapping by several threads).  Runs of plain decode casts are evaluated as a group: all
+    their packed bytes are uploaded, then ONE launch plan decodes them (one kernel launch per block type
+    instead of one per tensor), up to `group_bytes` of decoded output at a time."""
 
-    def __init__(self, tensors, device):
+    def __init__(self, tensors, device, group_bytes=4 << 30):
         import torch
         self._torch = torch
         self._tensors = tensors
         self._device = device
+        self._group_bytes = group_bytes
         size = max(t.nbytes for _, t in tensors)
         self._bufs = [torch.empty(size, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._free = queue.Queue()
@@ -476,30 +490,95 @@ class _Producer:
         self._ready = queue.Queue()
         self._held = None
         self._stop = False
+        self.launches = 0             # decode kernel launches issued through launch plans
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
+    def _units(self):
+        """File order, cut into units: a list of decode casts that share a plan, or one other tensor."""
+        units, run, held = [], [], 0
+        for name, t in self._tensors:
+            if isinstance(t.data, Cast) and t.data.is_decode() and t.data.src.arr is not None:
+                if run and held + t.nbytes > self._group_bytes:
+                    units.append(run)
+                    run, held = [], 0
+                run.append((name, t))
+                held += t.nbytes
+            else:
+                if run:
+                    units.append(run)
+                    run, held = [], 0
+                units.append((name, t))
+        if run:
+            units.append(run)
+        return units
+
+    def _emit(self, name, t, out, stream):
+        """Device bytes -> the next free pinned buffer -> the writer.  False when asked to stop."""
+        b = self._free.get()
+        if b is None or self._stop:
+            return False
+        assert out.numel() == t.nbytes, (name, out.numel(), t.nbytes)
+        host = self._bufs[b][:out.numel()]
+        host.copy_(out, non_blocking=True)
+        stream.synchronize()
+        self._ready.put((b, host.numpy()))
+        return True
+
     def _run(self):
         torch = self._torch
+        from .quants import Batch, Context
+        dev = f"cuda:{self._device}"
+        ctx = None
         try:
             with torch.cuda.device(self._device):
+                ctx = Context(self._device, 64 << 20)
+
+                def up(arr):
+                    d = torch.empty(arr.size, dtype=torch.uint8, device=dev)
+                    ctx.upload_async(d, arr)
+                    ctx.sync()
+                    return d
+
                 stream = torch.cuda.Stream()
                 with torch.cuda.stream(stream):
-                    for name, t in self._tensors:
-                        b = self._free.get()
-                        if b is None or self._stop:
-                            return
-                        try:
-                            out = t.data.device(f"cuda:{self._device}")
-                        except ValueError as e:
-                            raise ValueError(f"{name}: {e}") from None
-                        assert out.numel() == t.nbytes, (name, out.numel(), t.nbytes)
-                        host = self._bufs[b][:out.numel()]
-                        host.copy_(out, non_blocking=True)
-                        stream.synchronize()
-                        self._ready.put((b, host.numpy()))
+                    for unit in self._units():
+                        if isinstance(unit, list):
+                            srcs, outs = [], []
+                            for name, t in unit:
+                                c = t.data
+                                d = torch.empty(c.src.arr.size, dtype=torch.uint8, device=dev)
+                                ctx.upload_async(d, c.src.arr)
+                                srcs.append(d)
+                                n = c.src.arr.size // block_bytes(c.from_ty) * block_elems(c.from_ty)
+                                outs.append(torch.empty(n, dtype=_torch_dtype(c.to_ty), device=dev))
+                            ctx.sync()
+                            by_out = {}
+                            for (name, t), sd, od in zip(unit, srcs, outs):
+                                by_out.setdefault(t.data.to_ty, []).append((t.data.from_ty, sd, od))
+                            plans = [Batch(v, k) for k, v in by_out.items()]
+                            for p in plans:
+                                p.run(stream.cuda_stream)
+                                self.launches += p.launches
+                            for (name, t), od in zip(unit, outs):
+                                if not self._emit(name, t, od.view(torch.uint8), stream):
+                                    return
+                            for p in plans:
+                                p.close()
+                            del srcs, outs
+                        else:
+                            name, t = unit
+                            try:
+                                out = t.data.device(dev, up)
+                            except ValueError as e:
+                                raise ValueError(f"{name}: {e}") from None
+                            if not self._emit(name, t, out, stream):
+                                return
         except BaseException as e:
             self._ready.put(e)
+        finally:
+            if ctx is not None:
+                ctx.close()
 
     def next(self):
         """The next tensor's bytes; the buffer handed out before it goes back to the producer."""

@@ -1028,6 +1028,47 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
     return rc;
 }
 
+ggq_status ggq_upload_async(ggq_ctx *c, void *d_dst, const void *h_src, size_t bytes) {
+    if (!c) return GGQ_INVALID;
+    if (bytes == 0) return GGQ_OK;
+    if (!d_dst || !h_src) return GGQ_INVALID;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t *s = (const uint8_t *)h_src;
+    uint8_t *d = (uint8_t *)d_dst;
+    bool src_pinned = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, h_src) == hipSuccess) src_pinned = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    ggq_status rc = GGQ_OK;
+    int slot = c->busy[0] && !c->busy[1] ? 1 : 0;
+    for (size_t done = 0; done < bytes && rc == GGQ_OK;) {
+        const size_t n = std::min(c->in_cap, bytes - done);
+        hipStream_t q = c->stream[slot];
+        const void *from = s + done;
+        if (!src_pinned) {
+            if (c->busy[slot]) {
+                if (!hip_ok(hipEventSynchronize(c->done[slot]), "hipEventSynchronize")) { rc = GGQ_DEVICE; break; }
+                c->busy[slot] = false;
+            }
+            copy_pool().copy(c->h_in[slot], from, n);
+            from = c->h_in[slot];
+        }
+        if (!hip_ok(hipMemcpyAsync(d + done, from, n, hipMemcpyHostToDevice, q), "H2D")) { rc = GGQ_DEVICE; break; }
+        if (!src_pinned) {
+            if (!hip_ok(hipEventRecord(c->done[slot], q), "hipEventRecord")) { rc = GGQ_DEVICE; break; }
+            c->busy[slot] = true;
+        }
+        done += n;
+        slot ^= 1;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
 // ---- streamed host -> device, no allocation -----------------------------------------
 ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, size_t dst_elems, const void *h_src,
                                   size_t src_blocks, void *hip_stream) {

@@ -343,31 +343,74 @@ def plan_shards(alignment, meta_kvs, tensors, max_tensor_count=2 ** 64 - 1, max_
 
 # ---- whole-file decode ---------------------------------------------------------------------
 
-def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None):
+def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None, group_bytes=1 << 30,
+                    stats=None):
     """Decode every tensor of an open GGuf that holds data and has a block type this library
-    decodes, streamed host -> device through one Context; returns {name: device tensor}.
-    F32 tensors are copied as they are (the reference's cast leaves them alone too)."""
+    decodes; returns {name: device tensor}.  F32 tensors are copied as they are (the reference's
+    cast leaves them alone too).
+
+    The packed bytes are streamed host -> device through one Context (pinned staging, helper
+    threads); tensors are gathered into groups of about `group_bytes` packed bytes and each group is
+    decoded by ONE launch plan -- one kernel launch per block type present, not one per tensor --
+    while the next group's bytes are still on their way.  `stats`, if a dict, receives the counts."""
     import torch
-    from .quants import Context, SUPPORTED
+    from .quants import Batch, Context, SUPPORTED
     dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out]
+    out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out]
+    supported = {int(x) for x in SUPPORTED}
+    dev = f"cuda:{device}"
     ctx = Context(device, staging_bytes)
-    res = {}
+    res, plans = {}, []
+    counts = {"tensors": 0, "groups": 0, "launches": 0, "packed_bytes": 0}
+
+    def flush(group):
+        if not group:
+            return
+        offs, total = [], 0
+        for t, _ in group:
+            offs.append(total)
+            total += (t.nbytes + 31) & ~31
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        for (t, _), o in zip(group, offs):
+            ctx.upload_async(arena[o:o + t.nbytes], t.bytes())
+        ctx.sync()                      # this group's bytes have landed; its decode overlaps the next group's upload
+        b = Batch([(t.ty, arena[o:o + t.nbytes], dst) for (t, dst), o in zip(group, offs)], out_ty)
+        b.run()
+        plans.append((b, arena))
+        counts["groups"] += 1
+        counts["launches"] += b.launches
+        counts["packed_bytes"] += total
+
     try:
         with torch.cuda.device(device):
+            group, held = [], 0
             for t in gguf.tensors:
                 if only is not None and t.name not in only:
                     continue
                 if not t.ptr:
                     continue
                 if t.ty == GGmlType.F32:
-                    res[t.name] = torch.from_numpy(t.bytes().view(np.float32).copy()).to(f"cuda:{device}")
+                    dst = torch.empty(t.numel, dtype=torch.float32, device=dev)
+                    ctx.upload_async(dst.view(torch.uint8), t.bytes())
+                    res[t.name] = dst
                     continue
-                if t.ty not in [int(x) for x in SUPPORTED]:
+                if t.ty not in supported:
                     continue
-                dst = torch.empty(t.numel, dtype=dt, device=f"cuda:{device}")
-                ctx.dequantize_async(t.ty, dst, t.bytes())
+                dst = torch.empty(t.numel, dtype=dt, device=dev)
                 res[t.name] = dst
+                group.append((t, dst))
+                held += t.nbytes
+                counts["tensors"] += 1
+                if held >= group_bytes:
+                    flush(group)
+                    group, held = [], 0
+            flush(group)
             ctx.sync()
+            torch.cuda.synchronize()
     finally:
+        for b, _ in plans:
+            b.close()
         ctx.close()
+    if stats is not None:
+        stats.update(counts)
     return res

@@ -323,6 +323,16 @@ class Context:
         check(lib.ggq_dequantize_async(self._h, int(ty), int(_out_type(dst)), dst.data_ptr(),
                                        dst.numel(), sp, nbytes // bb))
 
+    def upload_async(self, dst, src_host):
+        """Copy host bytes (numpy array / CPU tensor, pageable or pinned) into a uint8 device tensor."""
+        sp, sn, ss, s_dev = _describe(src_host)
+        dp, dn, ds, d_dev = _describe(dst)
+        if s_dev or not d_dev:
+            raise ValueError("src must be host memory and dst device memory")
+        if sn * ss != dn * ds:
+            raise LengthMismatch()
+        check(lib.ggq_upload_async(self._h, dp, sp, sn * ss))
+
     def sync(self):
         check(lib.ggq_sync(self._h))
 

@@ -191,6 +191,13 @@ ggq_status ggq_ctx_create(int device, size_t staging_bytes, ggq_ctx **out);
 ggq_status ggq_dequantize_async(ggq_ctx *ctx, uint32_t ggml_type, uint32_t out_type,
                                 void *d_dst, size_t dst_elems,
                                 const void *h_src, size_t src_blocks);
+/* Copies `bytes` of host memory to d_dst through the same pipeline, without decoding: pageable
+ * memory is staged through the context's pinned slots (the staging memcpy of one chunk overlaps the
+ * DMA of the one before), page-locked memory is read in place.  For callers that bring many packed
+ * tensors to the device and then decode them with ONE ggq_batch_* plan (one launch per block type)
+ * instead of one launch per tensor.  Source lifetime and ggq_sync as for ggq_dequantize_async.
+ * No counterpart in the reference (its tensors stay in the file mapping, xtask/src/utils/read.rs:49-55). */
+ggq_status ggq_upload_async(ggq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 ggq_status ggq_sync(ggq_ctx *ctx);
 void ggq_ctx_destroy(ggq_ctx *ctx);
 

@@ -35,8 +35,16 @@ def test_file_to_device_tensors(tmp_path, oracle):
                                    "llama.block_count": 4}, tensors))
     with G.GGuf(path) as g:
         assert g.meta("general.file_type") == 15 and len(g.tensors) == len(spec)
-        for out, okind in (("f32", None), ("f16", "f16")):
-            res = G.dequantize_file(g, out=out, staging_bytes=1 << 20)
+        # one group: one kernel launch per block type present (8) plus one per F16 / BF16 tensor (2), for 13 tensors
+        stats = {}
+        G.dequantize_file(g, stats=stats)
+        assert (stats["tensors"], stats["groups"], stats["launches"]) == (13, 1, 10)
+        for out, okind, group_bytes in (("f32", None, 1 << 30), ("f16", "f16", 150_000), ("f32", None, 1)):
+            stats = {}
+            res = G.dequantize_file(g, out=out, staging_bytes=1 << 20, group_bytes=group_bytes, stats=stats)
+            assert stats["groups"] == {1 << 30: 1, 1: 13}.get(group_bytes, stats["groups"]) and stats["groups"] >= 1
+            if group_bytes == 150_000:
+                assert 2 <= stats["groups"] < 13
             assert set(res) == {n for n, _, _ in spec}
             for name, (ty, data) in packed.items():
                 got = res[name]
@@ -49,3 +57,30 @@ def test_file_to_device_tensors(tmp_path, oracle):
                 else:
                     want = oracle.dequantize(ty, data, oracle.F16)
                     assert same_bits16(got.view(torch.int16).cpu().numpy().view(np.uint16), want, "f16"), name
+
+
+def test_upload_async_pageable_and_pinned():
+    """ggq_upload_async: bytes arrive unchanged, from pageable memory (staged, several chunks, odd sizes
+    and offsets) and from page-locked memory (read in place)."""
+    import torch
+    import gguf_amd as g
+    rng = np.random.default_rng(3)
+    ctx = g.Context(0, staging_bytes=2 << 20)
+    try:
+        work = []
+        for n, off in ((1, 0), (5_000_001, 3), (1 << 20, 1), ((2 << 20) + 17, 0), (12345, 7)):
+            host = rng.integers(0, 256, n + off, dtype=np.uint8)[off:]
+            dst = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            ctx.upload_async(dst, host)
+            work.append((host.copy(), dst))
+        pinned = torch.from_numpy(rng.integers(0, 256, 3_000_000, dtype=np.uint8)).pin_memory()
+        dst = torch.zeros(3_000_000, dtype=torch.uint8, device="cuda")
+        ctx.upload_async(dst, pinned)
+        ctx.sync()
+        assert np.array_equal(dst.cpu().numpy(), pinned.numpy())
+        for host, dst in work:
+            assert np.array_equal(dst.cpu().numpy(), host)
+        with pytest.raises(g.LengthMismatch):
+            ctx.upload_async(dst, np.zeros(5, dtype=np.uint8))
+    finally:
+        ctx.close()
