@@ -1,0 +1,43 @@
+"""The kernels beside the f32 decode -- quantize, widen, narrow, the permute_qk row gather -- run a few
+times each on 1 Gi elements, for `rocprofv3 --kernel-trace --stats` (profiles/summarize_misc.py prices
+the averages against 8 TB/s).  Run on the GPU box."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gguf_amd as g  # noqa: E402
+from gguf_amd import rearrange as R  # noqa: E402
+from gguf_amd.quants import GGmlType as T  # noqa: E402
+
+n = 1 << 30
+reps = 12
+x = torch.randn(n, device="cuda") * 0.02
+bytes_per_launch = {}
+
+for ty in (T.Q4_0, T.Q8_0):
+    dst = torch.empty(n // 32 * g.block_bytes(ty), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        g.quantize_slice(ty, dst, x)
+    bytes_per_launch[f"quant_one<ggq::Enc{ty.name}, ggq::InF32"] = n * 4 + dst.numel()
+torch.cuda.synchronize()
+
+h = torch.empty(n, dtype=torch.float16, device="cuda")
+for _ in range(reps):
+    g.quantize_slice(T.F16, h.view(torch.uint8), x)            # narrow f32 -> f16
+bytes_per_launch["narrow_vec<ggq::InF32, ggq::OutF16"] = n * 6
+for _ in range(reps):
+    g.dequantize_slice(T.F16, x, h.view(torch.uint8))          # widen f16 -> f32
+bytes_per_launch["widen_vec<false, ggq::OutF32"] = n * 6
+torch.cuda.synchronize()
+
+# permute_qk: a [4096, rows] Q4_K tensor (2304-byte rows), 1 Gi elements
+rows = n // 4096
+src = torch.randint(0, 255, (rows * 2304,), dtype=torch.uint8, device="cuda")
+for _ in range(reps):
+    out = R.permute_qk(T.Q4K, 4096, rows, rows // 128, src)
+bytes_per_launch["permute_qk_rows<16"] = 2 * rows * 2304
+torch.cuda.synchronize()
+print(json.dumps(bytes_per_launch))
