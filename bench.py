@@ -56,6 +56,9 @@ def parse():
                     help="timed steps of the streamed (host -> device, PCIe-inclusive) leg; 0 = skip it")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N > 1 with strong scaling: skip the secondary weak-scaling measurement")
+    ap.add_argument("--gather", type=int, default=0, metavar="G",
+                    help="N > 1: after the decode, time G all-gathers of the decoded shares (every rank ends with every "
+                         "tensor; RCCL over xGMI).  Opt-in and reported on its own: the decode needs no exchange")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -191,7 +194,7 @@ class Share:
     """One rank's pieces of the job: packed blocks and decoded output resident in HBM, one launch
     plan per block type (largest first)."""
 
-    def __init__(self, pieces, out_name, dev, seed_base):
+    def __init__(self, pieces, out_name, dev, seed_base, arena_bytes=None):
         import torch
         import gguf_amd as g
         from gguf_amd import synth
@@ -203,18 +206,23 @@ class Share:
         self.pieces = pieces
         self.elems = sum(p.elems for p in pieces)
         self.packed_bytes = sum(p.blocks * block_bytes(p.ggml_type) for p in pieces)
-        need = self.elems * self.ob + self.packed_bytes
+        need = max(self.elems * self.ob, arena_bytes or 0) + self.packed_bytes
         free = torch.cuda.mem_get_info(dev)[0]
         if need > 0.97 * free:
             raise MemoryError(f"this share needs {need / 2**30:.1f} GiB of HBM, {free / 2**30:.1f} GiB are free; "
                               f"use more GPUs (strong scaling) or --out f16")
-        self.dst_all = torch.empty(self.elems, dtype=out_dt, device=dev)
+        # decoded pieces in share order, each 256-byte aligned, in one arena (gguf_amd.shard.arena_layout);
+        # `arena_bytes` pads it to the largest share of the job when the shares are to be gathered
+        offs, at = [], 0
+        for p in pieces:
+            offs.append(at)
+            at += (p.elems * self.ob + 255) & ~255
+        self.arena = torch.empty(max(at, arena_bytes or 0), dtype=torch.uint8, device=dev)
+        self.dst_all = self.arena[:at].view(out_dt)
         self.by_type = {}
-        at = 0
-        for i, p in enumerate(pieces):
+        for i, (p, o) in enumerate(zip(pieces, offs)):
             src = synth.random_blocks_device(p.ggml_type, p.blocks, seed_base + i, dev)
-            dst = self.dst_all[at:at + p.elems]
-            at += p.elems
+            dst = self.arena[o:o + p.elems * self.ob].view(out_dt)
             self.by_type.setdefault(int(p.ggml_type), []).append((p.ggml_type, src, dst))
         self.order = sorted(self.by_type, key=lambda t: -sum(x[2].numel() for x in self.by_type[t]))
         self.plans = [(ty, g.Batch(self.by_type[ty], self.out_ty)) for ty in self.order]
@@ -384,8 +392,10 @@ def main():
     # ---- the job, dealt to ranks by the index partition -----------------------------
     base, items, label = job_items(args.workload, args.scaling, world)
     shares = shard.partition(items, world, out_bytes=4 if args.out == "f32" else 2)
+    gathering = args.gather > 0 and world > 1
+    where, padded = shard.arena_layout(shares, 4 if args.out == "f32" else 2)
     try:
-        share = Share(shares[rank], args.out, dev, 0xC0FFEE04 + 100000 * rank)
+        share = Share(shares[rank], args.out, dev, 0xC0FFEE04 + 100000 * rank, padded if gathering else None)
     except MemoryError as e:
         sys.exit(f"rank {rank}: {e}")
     ob = share.ob
@@ -422,6 +432,40 @@ def main():
             }
         except Exception as e:          # never lose the main line to the secondary leg
             streamed = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            dist.barrier()
+
+    # opt-in: every rank ends with every rank's decoded share (one large all-gather)
+    gather = None
+    if gathering:
+        try:
+            share.poison()
+            share.step(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if shared:      # rehearsal: ranks share a GPU, which RCCL refuses; host copies over gloo carry the logic
+                arena, group, how = share.arena.cpu(), None, "gloo on host copies (REHEARSAL)"
+            else:
+                arena, group, how = share.arena, dist.new_group(backend="nccl"), "RCCL all_gather_into_tensor over xGMI"
+            full = shard.gather_arenas(arena, world, group)          # warm-up: communicator set-up
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.gather):
+                full = shard.gather_arenas(arena, world, group)
+            fence()
+            g_elapsed = max_over_ranks(time.perf_counter() - t0) / args.gather
+            # every rank's row must be that rank's arena: compare 64-bit sums of the rows with the owners' own
+            mine = share.arena.view(torch.int64).sum().cpu().reshape(1)
+            sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(sums, mine)
+            rows = full.view(world, -1).view(torch.int64).sum(dim=1).cpu()
+            g_ok = all(int(rows[r]) == int(sums[r]) for r in range(world))
+            _, g_ok = all_ok(0, g_ok)
+            gather = {"collective": how, "steps": args.gather, "ms": round(g_elapsed * 1e3, 3),
+                      "arena_bytes_per_rank": int(padded), "received_GBps_per_gpu": round((world - 1) * padded / g_elapsed / 1e9, 2),
+                      "whole_job_GBps": round(world * (world - 1) * padded / g_elapsed / 1e9, 2), "verified": g_ok}
+            del full
+        except Exception as e:
+            gather = {"error": f"{type(e).__name__}: {e}"}
         if world > 1:
             dist.barrier()
 
@@ -501,6 +545,10 @@ def main():
         if streamed is not None:
             rec["streamed"] = streamed
             if streamed.get("verified") and not streamed["verified"]["ok"]:
+                rc = 1
+        if gather is not None:
+            rec["gather"] = gather
+            if gather.get("verified") is False:
                 rc = 1
         if weak is not None:
             rec["secondary"] = weak

@@ -91,3 +91,37 @@ def imbalance(shares, out_bytes=4):
              for s in shares]
     mean = sum(loads) / len(loads)
     return max(loads) / mean if mean else 1.0
+
+
+# ---- opt-in gather ---------------------------------------------------------------------
+# The decode needs no exchange; a caller that wants every rank to hold every decoded tensor asks for
+# it explicitly.  Each rank keeps its pieces, in share order, in ONE contiguous arena padded to the
+# largest share, so the whole exchange is a single large all-gather (over RCCL / xGMI when the group
+# is an nccl group and the arenas are device tensors; xGMI is point to point, a ring all-gather is
+# bound by one link per GPU, ~150 GB/s, some 40 times below the decode rate -- hence opt-in).
+
+def arena_layout(shares, out_bytes=4):
+    """Where every piece lives after a gather: ({(tensor, block_begin): (rank, byte offset, bytes)},
+    padded arena bytes per rank).  Pieces sit in share order, each aligned to 256 bytes."""
+    where, sizes = {}, []
+    for r, s in enumerate(shares):
+        at = 0
+        for p in s:
+            n = p.elems * out_bytes
+            where[(p.tensor, p.block_begin)] = (r, at, n)
+            at += (n + 255) & ~255
+        sizes.append(at)
+    return where, (max(sizes) + 255) & ~255 if sizes else 0
+
+
+def gather_arenas(arena, world, group=None):
+    """All-gather of the ranks' padded arenas: returns a [world, arena.numel()] tensor that holds rank
+    r's arena in row r, on every rank.  `arena`: this rank's uint8 arena, the same (padded) length on
+    every rank; device tensors need an nccl group, host tensors a gloo group."""
+    import torch
+    import torch.distributed as dist
+    if arena.dtype != torch.uint8 or arena.dim() != 1:
+        raise ValueError("arena must be a flat uint8 tensor")
+    full = torch.empty((world, arena.numel()), dtype=torch.uint8, device=arena.device)
+    dist.all_gather_into_tensor(full.view(-1), arena, group=group)
+    return full

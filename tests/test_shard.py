@@ -108,3 +108,68 @@ def test_two_ranks_gloo_cover_the_model(oracle):
     for _, total, dg in res:
         assert total == want_elems
         assert dg == digest % (2 ** 62)
+
+
+def _gather_main(rank, ws, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        items = [(f"t{i}", ty, n) for i, (ty, n) in enumerate(
+            [(GGmlType.Q4K, 256 * 300), (GGmlType.Q6K, 256 * 77), (GGmlType.Q4_0, 32 * 1000),
+             (GGmlType.Q4K, 256 * 5), (GGmlType.Q8_0, 32 * 64)])]
+        shares = shard.partition(items, ws)
+        where, padded = shard.arena_layout(shares, 4)
+        # stand-in for the decode: element k of tensor t is the float 1000 * t + (k % 997)
+        arena = torch.zeros(padded, dtype=torch.uint8)
+        for p in shares[rank]:
+            r, off, n = where[(p.tensor, p.block_begin)]
+            assert r == rank
+            first = p.block_begin * block_elems(p.ggml_type)
+            vals = (torch.arange(first, first + p.elems) % 997 + 1000 * p.tensor).to(torch.float32)
+            arena[off:off + n] = vals.view(torch.uint8)
+        full = shard.gather_arenas(arena, ws)
+        ok = True
+        for (t, begin), (r, off, n) in where.items():
+            ty = items[t][1]
+            first = begin * block_elems(ty)
+            got = full[r, off:off + n].view(torch.float32)
+            want = (torch.arange(first, first + n // 4) % 997 + 1000 * t).to(torch.float32)
+            ok = ok and bool(torch.equal(got, want))
+        q.put((rank, ok, len(where)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_opt_in_gather_two_ranks_gloo():
+    """After the opt-in gather every rank can find every piece of every tensor (host tensors over gloo here;
+    device tensors over an nccl group take the same call)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and all(n >= 5 for _, _, n in res)
+
+
+def test_arena_layout_is_disjoint_and_aligned():
+    items = synth.workload("llama7b_q4_k_m")
+    shares = shard.partition(items, 8)
+    where, padded = shard.arena_layout(shares, 4)
+    assert padded % 256 == 0
+    per_rank = {}
+    for (t, b), (r, off, n) in where.items():
+        assert off % 256 == 0 and off + n <= padded
+        per_rank.setdefault(r, []).append((off, n))
+    for r, spans in per_rank.items():
+        spans.sort()
+        for (a, n), (b, _) in zip(spans, spans[1:]):
+            assert a + n <= b
+    assert sum(n for _, _, n in where.values()) == 6_738_149_376 * 4
