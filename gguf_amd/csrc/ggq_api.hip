@@ -1074,6 +1074,13 @@ ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, siz
                                   size_t src_blocks, void *hip_stream) {
     ggq_status st = check_slice(ty, out_ty, dst_elems, src_blocks);
     if (st != GGQ_OK) return st;
+    // the one-time set-up of the current device happens on every valid call, also an empty one, so that a
+    // caller can get it out of the way before it starts capturing a graph
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    NoallocDev nd;
+    st = noalloc_state(dev, nd);
+    if (st != GGQ_OK) return st;
     if (src_blocks == 0) return GGQ_OK;
     if (!d_dst || !h_src) return GGQ_INVALID;
     if ((uintptr_t)d_dst % 16 != 0) return GGQ_MISALIGNED;
@@ -1090,11 +1097,6 @@ ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, siz
         g_err = "ggq_dequantize_noalloc: h_src is not page-locked host memory";
         return GGQ_INVALID;
     }
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    NoallocDev nd;
-    st = noalloc_state(dev, nd);
-    if (st != GGQ_OK) return st;
     hipStream_t q = (hipStream_t)hip_stream;
     HIP_TRY(hipMemcpyAsync(nd.ptr, h_src, src_blocks * ti->bytes, hipMemcpyHostToDevice, q));
     return launch_out(ty, out_ty, d_dst, nd.ptr, src_blocks, nd.cus, q);

@@ -214,6 +214,8 @@ void ggq_ctx_destroy(ggq_ctx *ctx);
  * otherwise) and stay valid until the stream has passed the copy; src_blocks * block bytes
  * must not exceed GGQ_NOALLOC_MAX_BYTES (GGQ_TOO_LARGE otherwise -- split the tensor).
  * Otherwise the contract and the check order of ggq_dequantize_device apply (d_dst 16-byte aligned).
+ * The first valid call on a device looks up where that device holds the staging array (once per
+ * device); a call with src_blocks == 0 does only that, e.g. before a graph capture begins.
  * All calls on one GPU share that GPU's staging buffer: calls on the same stream are ordered
  * by the stream; calls that can overlap on one GPU (different streams, or several threads)
  * race on it and must be serialized by the caller. */

@@ -148,3 +148,40 @@ def test_limits_and_errors(torch_cuda):
     assert lib.ggq_dequantize_noalloc(16, 0, dst.data_ptr(), 1024, hp.data_ptr(), 4, None) == _lib.UNSUPPORTED
     assert lib.ggq_dequantize_noalloc(12, 0, dst.data_ptr() + 4, 768, hp.data_ptr(), 3, None) == _lib.MISALIGNED
     assert lib.ggq_dequantize_noalloc(12, 0, dst.data_ptr(), 0, hp.data_ptr(), 0, None) == _lib.OK
+
+
+def test_under_graph_capture(torch_cuda, oracle):
+    """What the entry point is for: the call is captured into a HIP graph (a host-to-device copy node and a
+    kernel node, nothing allocated) and replayed; the pinned source's CONTENT changes between replays, the
+    program's own eager work and synchronizations sit between them, and every replay must give the oracle's
+    bits."""
+    from gguf_amd import synth
+    from gguf_amd._lib import lib
+    t = torch_cuda
+    ty, blocks = 12, 30001
+    h = t.empty(blocks * 144, dtype=t.uint8).pin_memory()
+    dst = t.empty(blocks * 256, dtype=t.float32, device="cuda")
+    # one-time per-device set-up outside the capture (an empty call does just that)
+    assert lib.ggq_dequantize_noalloc(ty, 0, dst.data_ptr(), 0, h.data_ptr(), 0, None) == 0
+    h.numpy()[:] = synth.random_blocks(ty, blocks, 6000)
+    t.cuda.synchronize()
+    graph = t.cuda.CUDAGraph()
+    with t.cuda.graph(graph, capture_error_mode="thread_local"):
+        rc = lib.ggq_dequantize_noalloc(ty, 0, dst.data_ptr(), dst.numel(), h.data_ptr(), blocks,
+                                        t.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.ggq_last_error()
+    for rep in range(4):
+        p = synth.random_blocks(ty, blocks, 6001 + rep)
+        h.numpy()[:] = p
+        dst.fill_(-7.0)                                   # eager work between the replays
+        t.cuda.synchronize()
+        graph.replay()
+        t.cuda.synchronize()
+        want = oracle.dequantize(ty, p, threads=8)
+        assert same_bits(dst.cpu().numpy(), want), (rep, first_diff(dst.cpu().numpy(), want))
+        # an eager call of another type in between shares the staging array; the next replay must not care
+        p2 = synth.random_blocks(14, 777, 6100 + rep)
+        rc, d2 = run_noalloc(t, 14, t.float32, pinned_blocks(t, p2), 777)
+        assert rc == 0
+        t.cuda.synchronize()
+        assert same_bits(d2.cpu().numpy(), oracle.dequantize(14, p2, threads=8))

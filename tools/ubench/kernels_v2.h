@@ -536,4 +536,203 @@ struct UbVariant {
     std::vector<float> ms;
 };
 
+
+// XCD <-> memory locality probe.  Workgroups go to the 8 XCDs round robin (workgroup w -> XCD w % 8).
+// Each workgroup of 256 threads writes S chunks of 4 KiB; chunk index = (g * S + j) * 8 + (x + shift) % 8
+// with g = w / 8, x = w % 8: XCD x only ever writes chunks whose index is (x + shift) mod 8.  With S = 1 and
+// shift = 0 this is the plain one-store-per-thread fill.
+template <int S>
+__global__ __launch_bounds__(256) void k_fill_numa(float4v *dst, uint64_t n16, uint32_t shift, uint32_t gran16) {
+    const uint32_t w = blockIdx.x, g = w >> 3, x = w & 7;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
+    // gran16: chunk size in 16-byte units (256 = 4 KiB); a workgroup's 256 threads cover 4 KiB per store,
+    // so for larger chunks consecutive j stay inside one chunk first
+    const uint32_t per_chunk = gran16 / 256;          // stores (of 4 KiB) per chunk
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const uint32_t cj = j / per_chunk, within = j % per_chunk;
+        const uint64_t chunk = ((uint64_t)g * (S / per_chunk) + cj) * 8 + ((x + shift) & 7);
+        const uint64_t i = chunk * gran16 + within * 256 + threadIdx.x;
+        if (i < n16) __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
+// The same with THR threads: the workgroup's THR/256 quarter-K groups of 256 threads each write their own 4 KiB chunk
+// per store; all chunks of a workgroup are 8 chunks (32 KiB) apart.  GR = chunk size in units of 4 KiB is fixed at 1.
+template <int S, int THR>
+__global__ __launch_bounds__(THR) void k_fill_numa_t(float4v *dst, uint64_t n16) {
+    constexpr uint32_t H = THR / 256;                 // 4 KiB chunks per store instruction of the workgroup
+    const uint32_t w = blockIdx.x, g = w >> 3, x = w & 7;
+    const uint32_t h = threadIdx.x >> 8, t = threadIdx.x & 255;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const uint64_t chunk = (((uint64_t)g * S + j) * H + h) * 8 + x;
+        const uint64_t i = chunk * 256 + t;
+        if (i < n16) __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
+// chunk granularity probe: 256 threads, S stores, chunks of GR16 16-byte units (128 = 2 KiB, 256 = 4 KiB), the
+// workgroup's 4 KiB store covers 4096 / (16 * GR16) chunks, all of the workgroup's chunks 8 chunks apart
+template <int S, int GR16>
+__global__ __launch_bounds__(256) void k_fill_numa_g(float4v *dst, uint64_t n16) {
+    constexpr uint32_t CPS = 256 / GR16;               // chunks per store
+    const uint32_t w = blockIdx.x, g = w >> 3, x = w & 7;
+    const uint32_t c = threadIdx.x / GR16, t = threadIdx.x % GR16;
+    float4v v = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const uint64_t chunk = (((uint64_t)g * S + j) * CPS + c) * 8 + x;
+        const uint64_t i = chunk * GR16 + t;
+        if (i < n16) __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
+// ---- chunk-strided decode prototype -------------------------------------------------------------
+// The fills above say: a workgroup should write 4 KiB chunks that lie 8 chunks (32 KiB) apart, so
+// that the 8 workgroups of a group (one per XCD) together write one contiguous run, chunk by chunk
+// in round robin.  Here workgroup w = 8 g + x decodes chunks (g * C + k) * 8 + x, k = 0 .. C-1, of
+// the tensor; a chunk is 4 KiB of output = CHB whole blocks.  Every chunk's packed bytes are staged
+// into their own LDS region.  C = (THR / 256) * S: each group of 256 threads stores one chunk per step.
+template <class F, class O, int THR, int S>
+struct XGeom {
+    static constexpr uint32_t CH_ELEMS = 4096 / sizeof(typename O::T);
+    static constexpr uint32_t CHB = CH_ELEMS / F::N;
+    static constexpr uint32_t CHBYTES = CHB * F::BYTES;
+    static constexpr uint32_t H = THR / 256;
+    static constexpr uint32_t C = H * S;
+    static constexpr uint32_t RS = (CHBYTES + 15) / 16 + 2;      // 16-byte slots per region
+    static constexpr uint32_t TPC = THR / C;                     // loader threads per chunk
+    static constexpr uint32_t LPT = (RS + TPC - 1) / TPC;
+    static constexpr uint32_t TB = C * CHB;                      // blocks per workgroup
+    static constexpr uint32_t TBYTES = C * CHBYTES;
+    static constexpr uint32_t ELEMS = C * CH_ELEMS;
+    static constexpr uint32_t LINES = (TBYTES + 127) / 128 + 1;
+    static constexpr uint32_t TPW = THR / LINES;
+    static_assert(CH_ELEMS / O::EPL == 256, "256 threads store one chunk");
+    static_assert(CH_ELEMS % F::N == 0, "a chunk is a whole number of blocks");
+};
+
+template <class F, class O, int THR, int S, bool NT>
+__global__ __launch_bounds__(THR) void deq_one_x(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                 uint64_t nblocks, Prefetch pf) {
+    typedef XGeom<F, O, THR, S> G;
+    __shared__ uint4v lds[G::C * G::RS + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t w = blockIdx.x, g = w >> 3;
+    const uint32_t x = (uint32_t)(w & 7);
+    {   // stage: TPC threads per chunk
+        const uint32_t k = tid / G::TPC, lt = tid % G::TPC;
+        const uint64_t ck = (g * G::C + k) * 8 + x;
+        const uint64_t first = ck * G::CHB;
+        const uint32_t nb = first >= nblocks ? 0u : (uint32_t)(nblocks - first < G::CHB ? nblocks - first : G::CHB);
+        const uint8_t *sk = src + ck * G::CHBYTES;
+        const uint32_t off0 = (uint32_t)((uintptr_t)sk & 15u);
+        const uint4v *base16 = (const uint4v *)(sk - off0);
+        const uint32_t nslots = nb ? (off0 + nb * F::BYTES + 15u) >> 4 : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < G::LPT; ++q) {
+            const uint32_t sl = lt + G::TPC * q;
+            if (sl < nslots) lds[k * G::RS + sl] = base16[sl];
+        }
+    }
+    // burst prefetch over the linear packed bytes, unchanged: slice tt = bytes [tt * TBYTES, (tt + 1) * TBYTES)
+    uint32_t touch = 0;
+    if (pf.period) {
+        const uint32_t ph = (uint32_t)(w % pf.period);
+        const uint32_t nbw = (pf.period + G::TPW - 1) / G::TPW;
+        if (ph < nbw) {
+            const uint32_t j = tid / G::LINES, l = tid % G::LINES;
+            const uint32_t kk = ph * G::TPW + j;
+            if (j < G::TPW && kk < pf.period) {
+                const uint64_t tt = w - ph + pf.lead + kk;
+                if ((tt + 1) * G::TB <= nblocks) {
+                    const uint8_t *base = src + tt * G::TBYTES;
+                    const uint8_t *line = (const uint8_t *)((uintptr_t)base & ~(uintptr_t)127) + 128u * l;
+                    if (line < base + G::TBYTES) touch = *(const uint32_t *)line;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    LdsBytes r{(const uint32_t *)lds};
+    const uint32_t h = tid >> 8, tt = tid & 255u;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)S; ++i) {
+        const uint32_t k = i * G::H + h;
+        const uint64_t ck = (g * G::C + k) * 8 + x;
+        const uint64_t first = ck * G::CHB;
+        const uint32_t nb = first >= nblocks ? 0u : (uint32_t)(nblocks - first < G::CHB ? nblocks - first : G::CHB);
+        const uint32_t el = tt * O::EPL, bt = el / F::N, e = el % F::N;
+        if (bt < nb) {
+            const uint32_t off0 = (uint32_t)((uintptr_t)(src + ck * G::CHBYTES) & 15u);
+            const uint32_t b = k * G::RS * 16u + off0 + bt * F::BYTES;
+            const Scale sc = F::scale(r, b, e);
+            float y[O::EPL];
+            F::template vals<O::EPL / 4>(r, b, e, sc, y);
+            O::template store<NT>(dst + ck * G::CH_ELEMS + el, y);
+        }
+    }
+    asm volatile("" ::"v"(touch));
+}
+
+// ---- scale-table prototype ------------------------------------------------------------------------
+// The shipped kernel evaluates F::scale (header f16s, 6-bit scale unpack, one or two multiplies: 20-30
+// VALU instructions) in every thread for every 4 (8) elements.  Here the distinct scales of the tile --
+// TB * N / SUB of them -- are computed once by the first threads after the staging barrier and kept in LDS;
+// the decode reads its pair with one ds_read_b64.
+template <class F, class O, bool NT, uint32_t SUB>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_tab(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                          uint64_t nblocks, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    constexpr uint32_t SPB = F::N / SUB, ENT = G::TB * SPB;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    __shared__ float2v tab[ENT];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    const uint8_t *ts = src + t * G::TBYTES;
+    typename O::T *out = dst + t * G::ELEMS;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t off0 = (uint32_t)((uintptr_t)ts & 15u);
+    const uint4v *base16 = (const uint4v *)(ts - off0);
+    const uint32_t nslots = (off0 + nblk * F::BYTES + 15u) >> 4;
+#pragma unroll
+    for (uint32_t k = 0; k < G::LPT; ++k) {
+        uint32_t sl = tid + WG_THREADS * k;
+        if (sl < nslots) lds[sl] = base16[sl];
+    }
+    uint32_t touch = 0;
+    if (line != nullptr) touch = *(const uint32_t *)line;
+    __syncthreads();
+    LdsBytes r{(const uint32_t *)lds};
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < ENT; q0 += WG_THREADS) {
+        const uint32_t q = q0 + tid;
+        if (q < nblk * SPB) {
+            const Scale sc = F::scale(r, off0 + (q / SPB) * F::BYTES, (q % SPB) * SUB);
+            tab[q] = float2v{sc.a, sc.c};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
+        uint32_t el = (i * WG_THREADS + tid) * O::EPL;
+        uint32_t bt = el / F::N, e = el % F::N;
+        if (bt < nblk) {
+            uint32_t b = off0 + bt * F::BYTES;
+            const float2v tv = tab[bt * SPB + e / SUB];
+            const Scale sc{tv.x, tv.y};
+            float y[O::EPL];
+            F::template vals<O::EPL / 4>(r, b, e, sc, y);
+            O::template store<NT>(out + el, y);
+        }
+    }
+    asm volatile("" ::"v"(touch));
+}
+
 }  // namespace ggq

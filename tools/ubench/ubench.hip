@@ -686,6 +686,169 @@ int main(int argc, char **argv) {
     FSHOT(false, 1, true, "cal fill shot plain S1")
     FSHOT(true, 2, true, "probe fill shot nt S2")
     FSHOT(false, 2, true, "probe fill shot plain S2")
+    // ---- XCD <-> memory locality probes
+    {
+        char label[96];
+        for (uint32_t shift = 0; shift < 8; ++shift) {
+            std::snprintf(label, sizeof label, "numa S1 g4K shift%u", shift);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((k_fill_numa<1>), dim3((unsigned)(n16 / 256)), dim3(256), 0, s,
+                                                 (float4v *)d_out, n16, shift, 256u); }, {}});
+        }
+        for (uint32_t shift : {0u, 1u, 3u}) {
+            std::snprintf(label, sizeof label, "numa S4 g4K shift%u", shift);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((k_fill_numa<4>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, s,
+                                                 (float4v *)d_out, n16, shift, 256u); }, {}});
+            std::snprintf(label, sizeof label, "numa S2 g4K shift%u", shift);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((k_fill_numa<2>), dim3((unsigned)(n16 / 512)), dim3(256), 0, s,
+                                                 (float4v *)d_out, n16, shift, 256u); }, {}});
+            std::snprintf(label, sizeof label, "numa S4 g8K shift%u", shift);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((k_fill_numa<4>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, s,
+                                                 (float4v *)d_out, n16, shift, 512u); }, {}});
+            std::snprintf(label, sizeof label, "numa S4 g16K shift%u", shift);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((k_fill_numa<4>), dim3((unsigned)(n16 / 1024)), dim3(256), 0, s,
+                                                 (float4v *)d_out, n16, shift, 1024u); }, {}});
+        }
+    }
+    {
+#define NUMAT(S, THR, LABEL)                                                                                \
+        vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                        \
+                          hipLaunchKernelGGL((k_fill_numa_t<S, THR>), dim3((unsigned)(n16 / (THR * S))), dim3(THR), 0, s, \
+                                             (float4v *)d_out, n16); }, {}});
+        NUMAT(1, 256, "numat S1 thr256")
+        NUMAT(2, 256, "numat S2 thr256")
+        NUMAT(3, 256, "numat S3 thr256")
+        NUMAT(4, 256, "numat S4 thr256")
+        NUMAT(8, 256, "numat S8 thr256")
+        NUMAT(1, 512, "numat S1 thr512")
+        NUMAT(2, 512, "numat S2 thr512")
+        NUMAT(4, 512, "numat S4 thr512")
+        NUMAT(1, 1024, "numat S1 thr1024")
+        NUMAT(2, 1024, "numat S2 thr1024")
+#define NUMAG(S, GR, LABEL)                                                                                 \
+        vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                        \
+                          hipLaunchKernelGGL((k_fill_numa_g<S, GR>), dim3((unsigned)(n16 / (256 * S))), dim3(256), 0, s, \
+                                             (float4v *)d_out, n16); }, {}});
+        NUMAG(2, 256, "numag S2 g4K")
+        NUMAG(2, 128, "numag S2 g2K")
+        NUMAG(2, 64, "numag S2 g1K")
+        NUMAG(4, 128, "numag S4 g2K")
+    }
+    // ---- chunk-strided decode prototype against the shipped kernel
+    {
+#define XDEQ(F, O, THR, S, P, L, LABEL)                                                                      \
+        {                                                                                                   \
+            typedef XGeom<F, O, THR, S> G;                                                                  \
+            const uint64_t blocks = elems / F::N;                                                           \
+            const uint64_t groups = (blocks + 8ull * G::TB - 1) / (8ull * G::TB);                           \
+            const unsigned grid = (unsigned)(groups * 8);                                                   \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));         \
+            vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                \
+                              hipLaunchKernelGGL((deq_one_x<F, O, THR, S, true>), dim3(grid), dim3(THR), 0, s, \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}}); \
+        }
+        XDEQ(Q4K, OutF32, 512, 2, 768, 1280, "xdeq Q4K f32 thr512 S2 P768 L1280")
+        XDEQ(Q4K, OutF32, 512, 2, 0, 0, "xdeq Q4K f32 thr512 S2 nopf")
+        XDEQ(Q4K, OutF32, 256, 2, 1536, 2560, "xdeq Q4K f32 thr256 S2 P1536 L2560")
+        XDEQ(Q4K, OutF32, 256, 2, 0, 0, "xdeq Q4K f32 thr256 S2 nopf")
+        XDEQ(Q4K, OutF32, 512, 1, 1536, 2560, "xdeq Q4K f32 thr512 S1 P1536 L2560")
+        XDEQ(Q4K, OutF32, 256, 4, 768, 1280, "xdeq Q4K f32 thr256 S4 P768 L1280")
+        XDEQ(Q4K, OutF32, 512, 4, 384, 640, "xdeq Q4K f32 thr512 S4 P384 L640")
+        XDEQ(Q4K, OutF32, 256, 1, 3072, 5120, "xdeq Q4K f32 thr256 S1 P3072 L5120")
+        XDEQ(Q4K, OutF16, 512, 2, 768, 1280, "xdeq Q4K f16 thr512 S2 P768 L1280")
+        XDEQ(Q4K, OutF16, 256, 2, 1536, 2560, "xdeq Q4K f16 thr256 S2 P1536 L2560")
+        XDEQ(Q4K, OutF16, 512, 2, 0, 0, "xdeq Q4K f16 thr512 S2 nopf")
+        XDEQ(Q6K, OutF32, 512, 2, 1024, 1024, "xdeq Q6K f32 thr512 S2 P1024 L1024")
+        XDEQ(Q8_0, OutF32, 512, 2, 640, 1024, "xdeq Q8_0 f32 thr512 S2 P640 L1024")
+        SHIP(Q4K, OutF32, "xdeq ref ship Q4K f32")
+        SHIP(Q4K, OutF16, "xdeq ref ship Q4K f16")
+        SHIP(Q6K, OutF32, "xdeq ref ship Q6K f32")
+        SHIP(Q8_0, OutF32, "xdeq ref ship Q8_0 f32")
+    }
+    // ---- scale-table prototype against the shipped kernel
+    {
+#define TDEQ(F, O, SUB, LABEL)                                                                              \
+        {                                                                                                   \
+            typedef TileGeom<F, O> G;                                                                       \
+            const uint64_t blocks = elems / F::N;                                                           \
+            const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                 \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));         \
+            vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                \
+                              hipLaunchKernelGGL((deq_one_tab<F, O, true, SUB>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks,     \
+                                                 prefetch_for(F##_ID, sizeof(typename O::T) == 4 ? 0u : 1u, false)); }, {}}); \
+        }
+        TDEQ(Q4K, OutF32, 32, "tab Q4K f32")
+        TDEQ(Q4K, OutF16, 32, "tab Q4K f16")
+        TDEQ(Q5K, OutF32, 32, "tab Q5K f32")
+        TDEQ(Q5K, OutF16, 32, "tab Q5K f16")
+        TDEQ(Q6K, OutF32, 16, "tab Q6K f32")
+        TDEQ(Q6K, OutF16, 16, "tab Q6K f16")
+        TDEQ(Q3K, OutF32, 16, "tab Q3K f32")
+        TDEQ(Q3K, OutF16, 16, "tab Q3K f16")
+        TDEQ(Q2K, OutF32, 16, "tab Q2K f32")
+        TDEQ(IQ4XS, OutF32, 32, "tab IQ4XS f32")
+        TDEQ(Q4_0, OutF32, 32, "tab Q4_0 f32")
+        TDEQ(Q8_0, OutF32, 32, "tab Q8_0 f32")
+        TDEQ(Q8_0, OutF16, 32, "tab Q8_0 f16")
+        SHIP(Q4K, OutF32, "tab ref ship Q4K f32")
+        SHIP(Q4K, OutF16, "tab ref ship Q4K f16")
+        SHIP(Q5K, OutF32, "tab ref ship Q5K f32")
+        SHIP(Q5K, OutF16, "tab ref ship Q5K f16")
+        SHIP(Q6K, OutF32, "tab ref ship Q6K f32")
+        SHIP(Q6K, OutF16, "tab ref ship Q6K f16")
+        SHIP(Q3K, OutF32, "tab ref ship Q3K f32")
+        SHIP(Q3K, OutF16, "tab ref ship Q3K f16")
+        SHIP(Q2K, OutF32, "tab ref ship Q2K f32")
+        SHIP(IQ4XS, OutF32, "tab ref ship IQ4XS f32")
+        SHIP(Q4_0, OutF32, "tab ref ship Q4_0 f32")
+        SHIP(Q8_0, OutF32, "tab ref ship Q8_0 f32")
+        SHIP(Q8_0, OutF16, "tab ref ship Q8_0 f16")
+    }
+    // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
+    // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
+    {
+        static const uint32_t pads[] = {0, 36u << 10, 56u << 10, 100u << 10};
+        for (uint32_t X : pads) {
+            char label[96];
+            auto k1 = k_fill_lay<true, 2, 0, 512>;
+            auto k2 = k_fill_lay<true, 1, 0, 256>;
+            auto k3 = deq_one<Q4K, OutF32, true>;
+            auto k4 = deq_one<Q4K, OutF16, true>;
+            CK(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10));
+            CK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10));
+            CK(hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10));
+            CK(hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10));
+            std::snprintf(label, sizeof label, "occ fill S2 thr512 lds%uK", X >> 10);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL(k1, dim3((unsigned)(n16 / 1024)), dim3(512), X, s, (float4v *)d_out, n16); }, {}});
+            std::snprintf(label, sizeof label, "occ fill S1 thr256 lds%uK", X >> 10);
+            vs.push_back({label, (double)elems * 4, [=](hipStream_t s) {
+                              hipLaunchKernelGGL(k2, dim3((unsigned)(n16 / 256)), dim3(256), X, s, (float4v *)d_out, n16); }, {}});
+            {
+                typedef TileGeom<Q4K, OutF32> G;
+                const uint64_t blocks = elems / 256;
+                const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
+                std::snprintf(label, sizeof label, "occ deq Q4K f32 lds%uK", X >> 10);
+                vs.push_back({label, (double)elems * 4.5625, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL(k3, dim3(grid), dim3(WG_THREADS), X, s, (const uint8_t *)d_in, (float *)d_out,
+                                                     blocks, prefetch_for(Q4K_ID, 0u, false)); }, {}});
+            }
+            {
+                typedef TileGeom<Q4K, OutF16> G;
+                const uint64_t blocks = elems / 256;
+                const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
+                std::snprintf(label, sizeof label, "occ deq Q4K f16 lds%uK", X >> 10);
+                vs.push_back({label, (double)elems * 2.5625, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL(k4, dim3(grid), dim3(WG_THREADS), X, s, (const uint8_t *)d_in, (uint16_t *)d_out,
+                                                     blocks, prefetch_for(Q4K_ID, 1u, false)); }, {}});
+            }
+        }
+    }
     if (argc > 3 && std::strncmp(argv[3], "sw", 2) == 0) {
         vs.clear();
         add_sweep<Q4K, OutF32>(vs, "Q4K f32", d_in, d_out, elems);
@@ -734,7 +897,21 @@ int main(int argc, char **argv) {
     }
     if (argc > 3) {
         std::vector<Variant> keep;
-        for (auto &v : vs) if (v.name.find(argv[3]) != std::string::npos) keep.push_back(v);
+        // argv[3]: one or more substrings separated by commas; a variant is kept if its name holds any of them
+        std::vector<std::string> pats;
+        {
+            std::string a = argv[3];
+            size_t at = 0;
+            while (at <= a.size()) {
+                size_t c = a.find(',', at);
+                if (c == std::string::npos) c = a.size();
+                if (c > at) pats.push_back(a.substr(at, c - at));
+                at = c + 1;
+            }
+        }
+        for (auto &v : vs)
+            for (auto &p : pats)
+                if (v.name.find(p) != std::string::npos) { keep.push_back(v); break; }
         vs.swap(keep);
     }
 
