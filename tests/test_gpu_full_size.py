@@ -98,3 +98,42 @@ def test_llama70b_q4_k_m_iq4nl_f16(torch_cuda, oracle):
     f16 output (41 GB in + 138 GB out; the f32 form does not fit one GPU)."""
     n, elems = run_workload(torch_cuda, oracle, "llama70b_q4_k_m_iq4nl", "f16")
     assert elems == 68_975_329_280
+
+
+def test_tinyllama_f16_q8_0_round_trip_whole_model(torch_cuda, oracle):
+    """The first benchmark configuration at full size on the GPU: every 2-D F16 tensor of the reference's
+    TinyLlama asset (shapes from tests/golden/tinyllama_table.json; the asset ships no payload, so it is
+    seeded) goes F16 -> Q8_0 -> F32 on the device.  Checks: 2048 random blocks per tensor group against the
+    oracle's quantizer (bytes) and decoder (bits); the whole set against the reference's own round-trip
+    tolerance (q8_0.rs:50-53); the 1-D F32 norm tensors are not touched, as in the reference's cast."""
+    import json
+    import os
+    import gguf_amd as g
+    t = torch_cuda
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tinyllama_table.json")))["tensors"]
+    mats = [x for x in table if x["type"] == 1 and len(x["shape"]) == 2]
+    assert len(mats) == 90 and sum(1 for x in table if x["type"] == 0) == 45
+    gen = t.Generator(device="cuda")
+    gen.manual_seed(0xC0FFEE01)
+    total, worst = 0, 0.0
+    rng = np.random.default_rng(1)
+    for i, x in enumerate(mats):
+        n = x["shape"][0] * x["shape"][1]
+        assert x["shape"][0] % 32 == 0
+        w16 = (t.randn(n, device="cuda", generator=gen) * 0.02).to(t.float16)
+        q = t.empty(n // 32 * 34, dtype=t.uint8, device="cuda")
+        g.Q8_0.quantize_slice(q, w16)
+        y = t.empty(n, dtype=t.float32, device="cuda")
+        g.Q8_0.dequantize_slice(y, q)
+        worst = max(worst, float((y - w16.float()).abs().max()))
+        total += n
+        if i % 9 == 0 or n > 50_000_000:                    # sampled blocks of every ninth tensor and the two big ones
+            idx = t.from_numpy(rng.integers(0, n // 32, 2048)).cuda()
+            xin = w16.view(-1, 32)[idx].contiguous().view(t.int16).cpu().numpy().view(np.uint16).reshape(-1)
+            want_q = oracle.quantize(8, xin, in_ty=oracle.F16)
+            assert np.array_equal(q.view(-1, 34)[idx].cpu().numpy().reshape(-1), want_q), x["name"]
+            want = oracle.dequantize(8, want_q)
+            assert same_bits(y.view(-1, 32)[idx].cpu().numpy().reshape(-1), want), x["name"]
+        del w16, q, y
+    assert total == 1_099_956_224
+    assert worst < 4.5e-3
