@@ -193,11 +193,11 @@ ggq_status launch_widen(void *d_dst, const void *d_src, uint64_t n, int cus, hip
     typedef typename O::T T;
     const bool fast = ((uintptr_t)d_src % 8 == 0);
     const uint64_t n4 = fast ? n / 4 : 0;
-    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+    const uint64_t per_wg = (uint64_t)STREAM_THREADS * WidenShape<O>::STEPS;
     for (uint64_t i0 = 0; i0 < n4; i0 += kMaxGrid * per_wg) {
         uint64_t cnt = std::min(kMaxGrid * per_wg, n4 - i0);
         hipLaunchKernelGGL((widen_vec<BF16SRC, O, kNT>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)),
-                           dim3(WG_THREADS), 0, st, (const uint2v *)d_src + i0, (T *)d_dst + 4 * i0, cnt);
+                           dim3(STREAM_THREADS), 0, st, (const uint2v *)d_src + i0, (T *)d_dst + 4 * i0, cnt);
     }
     if (n4 * 4 < n) {
         uint64_t restn = n - n4 * 4;
@@ -252,10 +252,10 @@ ggq_status launch_narrow(void *d_dst, const void *d_src, uint64_t n, int cus, hi
     typedef typename In::T TI;
     typedef typename O::T TO;
     const uint64_t nvec = n / In::EPL * In::EPL;
-    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD * In::EPL;
+    const uint64_t per_wg = (uint64_t)STREAM_THREADS * In::EPL;
     for (uint64_t i0 = 0; i0 < nvec; i0 += kMaxGrid * per_wg) {
         uint64_t cnt = std::min(kMaxGrid * per_wg, nvec - i0);
-        hipLaunchKernelGGL((narrow_vec<In, O>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)), dim3(WG_THREADS),
+        hipLaunchKernelGGL((narrow_vec<In, O>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)), dim3(STREAM_THREADS),
                            0, st, (const TI *)d_src + i0, (TO *)d_dst + i0, cnt);
     }
     if (nvec < n) {
@@ -279,7 +279,7 @@ ggq_status launch_quant(uint32_t ty, void *d_dst, const void *d_src, uint64_t bl
         const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;                                      \
         for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                       \
             uint64_t n = std::min(kMaxGrid, ntiles - t0);                                          \
-            hipLaunchKernelGGL((quant_one<Q, In>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st,     \
+            hipLaunchKernelGGL((quant_one<Q, In>), dim3((uint32_t)n), dim3(G::THR), 0, st,         \
                                (const typename In::T *)d_src + t0 * G::ELEMS,                      \
                                (uint8_t *)d_dst + t0 * G::TBYTES, blocks - t0 * G::TB);            \
         }                                                                                          \
@@ -842,13 +842,13 @@ ggq_status ggq_permute_qk_device(uint32_t ty, uint64_t row_elems, uint64_t rows,
     const uintptr_t a = (uintptr_t)d_dst | (uintptr_t)d_src | (uintptr_t)rb;
     const uint32_t vec = a % 16 == 0 ? 16 : a % 4 == 0 ? 4 : a % 2 == 0 ? 2 : 1;
     const uint64_t pieces = rb / vec * rows;
-    const uint64_t per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+    const uint64_t per_wg = STREAM_THREADS;
     const uint64_t wgs = (pieces + per_wg - 1) / per_wg;
     hipStream_t q = (hipStream_t)hip_stream;
     uint8_t *o = (uint8_t *)d_dst;
     const uint8_t *i = (const uint8_t *)d_src;
     for (uint64_t w0 = 0; w0 < wgs; w0 += kMaxGrid) {
-        const dim3 grid((uint32_t)std::min(kMaxGrid, wgs - w0)), wg(WG_THREADS);
+        const dim3 grid((uint32_t)std::min(kMaxGrid, wgs - w0)), wg(STREAM_THREADS);
         const uint64_t first = w0 * per_wg;
         if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), grid, wg, 0, q, o, i, rb, rows, dh, first);
         else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), grid, wg, 0, q, o, i, rb, rows, dh, first);

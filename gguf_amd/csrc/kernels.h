@@ -239,26 +239,35 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restric
 }
 
 // ---- F16 / BF16 sources: plain widening, no LDS -------------------------------
-// (ggml-quants/src/structs/half.rs:19-21, 35-37).  Same one-shot shape: a thread
-// converts 4 consecutive elements per step from one 8-byte load into one 16-byte
-// store (f32 out; 8 bytes for 2-byte outputs), two steps per thread, so a workgroup
-// reads 8 KiB and writes 16 KiB, both contiguous.
+// (ggml-quants/src/structs/half.rs:19-21, 35-37).  A thread converts 4 consecutive elements per step
+// from one 8-byte load into one 16-byte store (f32 out; 8 bytes for 2-byte outputs).
 // Requires src 8-byte aligned and dst 16-byte aligned; n4 = elements / 4.
+// Shape of the streaming kernels that need no LDS (this one, narrow_vec, permute_qk_rows): 256 threads
+// and ONE step whose wider side is 16 bytes per thread, so a wave moves 1 KiB and ends -- measured
+// against the decode kernels' 512 x 2 shape on 1 Gi elements: f16 -> f32 6610 GB/s against 6075,
+// f32 -> f16 6640 against 6315, the row gather 6590-6690 against 6070-6120.  Where both sides are 8 bytes
+// per thread (f16 <-> bf16) two steps do better (6530 against 5710).  The decode kernels keep their shape:
+// their workgroups stage a tile through LDS behind a barrier, and with one store per thread that
+// fixed cost per wave dominates.
 // (Treating f16 as 64-byte blocks and going through the tile kernel measured +2 % without the
 // burst prefetch and -3 % with it: reads are a third of the traffic here, nothing to bunch.)
+constexpr uint32_t STREAM_THREADS = 256;
+template <class O> struct WidenShape { static constexpr uint32_t STEPS = O::EPL == 4 ? 1 : 2; };
+
 template <bool BF16SRC, class O, bool NT>
-__global__ __launch_bounds__(WG_THREADS) void widen_vec(const uint2v *__restrict__ src,
-                                                        typename O::T *__restrict__ dst, uint64_t n4) {
-    const uint64_t base = (uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x;
-    uint2v v[STORES_PER_THREAD];
+__global__ __launch_bounds__(STREAM_THREADS) void widen_vec(const uint2v *__restrict__ src,
+                                                            typename O::T *__restrict__ dst, uint64_t n4) {
+    constexpr uint32_t S = WidenShape<O>::STEPS;
+    const uint64_t base = (uint64_t)blockIdx.x * STREAM_THREADS * S + threadIdx.x;
+    uint2v v[S];
 #pragma unroll
-    for (uint32_t k = 0; k < STORES_PER_THREAD; ++k) {
-        uint64_t i = base + k * WG_THREADS;
+    for (uint32_t k = 0; k < S; ++k) {
+        uint64_t i = base + k * STREAM_THREADS;
         if (i < n4) v[k] = __builtin_nontemporal_load(src + i);
     }
 #pragma unroll
-    for (uint32_t k = 0; k < STORES_PER_THREAD; ++k) {
-        uint64_t i = base + k * WG_THREADS;
+    for (uint32_t k = 0; k < S; ++k) {
+        uint64_t i = base + k * STREAM_THREADS;
         if (i >= n4) continue;
         float y[4];
         if (BF16SRC) {

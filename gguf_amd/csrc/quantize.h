@@ -399,20 +399,34 @@ struct EncQ8K {
 };
 
 // ---- the kernel ------------------------------------------------------------------
-// LPT = 16-byte loads each thread has in flight
-template <class Q, class In, uint32_t LPT = STORES_PER_THREAD>
+// Workgroup shape per (encoder, input type): THR threads, each with LPT 16-byte loads in flight.
+// 256 threads beat 512 for every encoder (2-9 %, 1 Gi elements, `ubench ... "qsw "`); one load per thread
+// wins where the packed block is small against its input (Q4_0 and Q5_0 from f32: 6450 / 6360 GB/s against
+// 6020 / 6190 with the earlier 512 x 2; Q5_0 and Q5_1 from 16-bit input), two loads elsewhere.
+template <class Q, class In> struct QuantShape { static constexpr uint32_t THR = 256, LPT = 2; };
+template <> struct QuantShape<EncQ4_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ5_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ5_0, InF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ5_0, InBF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ5_1, InF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ5_1, InBF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+
+template <class Q, class In>
 struct QuantGeom {
-    static constexpr uint32_t ELEMS = WG_THREADS * In::EPL * LPT;
+    static constexpr uint32_t THR = QuantShape<Q, In>::THR, LPT = QuantShape<Q, In>::LPT;
+    static constexpr uint32_t ELEMS = THR * In::EPL * LPT;
     static constexpr uint32_t TB = ELEMS / Q::N;
     static constexpr uint32_t TBYTES = TB * Q::BYTES;
+    static_assert(ELEMS % Q::N == 0, "a tile is a whole number of blocks");
     static_assert(TBYTES % 16 == 0, "tiles leave as whole 16-byte stores");
 };
 
 // src: elements (16-byte aligned), dst: packed blocks (16-byte aligned), workgroup b -> tile b
-template <class Q, class In, uint32_t LPT = STORES_PER_THREAD, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__(WG_THREADS) void quant_one(const typename In::T *__restrict__ src,
-                                                        uint8_t *__restrict__ dst, uint64_t nblocks) {
-    typedef QuantGeom<Q, In, LPT> G;
+template <class Q, class In, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const typename In::T *__restrict__ src,
+                                                                    uint8_t *__restrict__ dst, uint64_t nblocks) {
+    typedef QuantGeom<Q, In> G;
+    constexpr uint32_t THR = G::THR, LPT = G::LPT;
     __shared__ __attribute__((aligned(16))) uint8_t lds[G::TBYTES];
     const uint32_t tid = threadIdx.x;
     const uint64_t t = blockIdx.x;
@@ -423,14 +437,14 @@ __global__ __launch_bounds__(WG_THREADS) void quant_one(const typename In::T *__
     float x[LPT][In::EPL];
 #pragma unroll
     for (uint32_t i = 0; i < LPT; ++i) {
-        uint32_t el = (i * WG_THREADS + tid) * In::EPL;
+        uint32_t el = (i * THR + tid) * In::EPL;
         if (el / Q::N < nblk) In::template load<NTL>(in + el, x[i]);
         else
             for (uint32_t k = 0; k < In::EPL; ++k) x[i][k] = 0.0f;
     }
 #pragma unroll
     for (uint32_t i = 0; i < LPT; ++i) {
-        uint32_t el = (i * WG_THREADS + tid) * In::EPL;
+        uint32_t el = (i * THR + tid) * In::EPL;
         uint32_t bt = el / Q::N;
         Q::template encode<In::EPL>(x[i], tid % LANES, lds + bt * Q::BYTES, bt < nblk);
     }
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(WG_THREADS) void quant_one(const typename In::T *__
     // packed tile -> global, 16 bytes per thread per pass; a short last tile ends in a byte tail
     const uint32_t nbytes = nblk * Q::BYTES;
     uint8_t *out = dst + t * G::TBYTES;
-    for (uint32_t o = tid * 16; o + 16 <= nbytes; o += WG_THREADS * 16) {
+    for (uint32_t o = tid * 16; o + 16 <= nbytes; o += THR * 16) {
         const uint4v v = *(const uint4v *)(lds + o);
         if (NTS) __builtin_nontemporal_store(v, (uint4v *)(out + o));
         else *(uint4v *)(out + o) = v;
@@ -448,24 +462,21 @@ __global__ __launch_bounds__(WG_THREADS) void quant_one(const typename In::T *__
 }
 
 // ---- f32 / f16 / bf16 -> f16 / bf16 (the 1-element "blocks", half.rs:10-17, 26-33) ----
+// One step per thread (see widen_vec for the measurements behind the shape).
 template <class In, class O>
-__global__ __launch_bounds__(WG_THREADS) void narrow_vec(const typename In::T *__restrict__ src,
-                                                         typename O::T *__restrict__ dst, uint64_t n) {
-    // n = elements, a multiple of In::EPL handled here; each thread converts EPL elements per step
-    const uint64_t base = ((uint64_t)blockIdx.x * WG_THREADS * STORES_PER_THREAD + threadIdx.x) * In::EPL;
-#pragma unroll
-    for (uint32_t i = 0; i < STORES_PER_THREAD; ++i) {
-        uint64_t el = base + (uint64_t)i * WG_THREADS * In::EPL;
-        if (el + In::EPL > n) continue;
-        float x[In::EPL];
-        In::template load<true>(src + el, x);
-        if constexpr (In::EPL == 4) {
-            uint2v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3])};
-            __builtin_nontemporal_store(o, (uint2v *)(dst + el));
-        } else {
-            uint4v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3]), O::pk(x[4], x[5]), O::pk(x[6], x[7])};
-            __builtin_nontemporal_store(o, (uint4v *)(dst + el));
-        }
+__global__ __launch_bounds__(STREAM_THREADS) void narrow_vec(const typename In::T *__restrict__ src,
+                                                             typename O::T *__restrict__ dst, uint64_t n) {
+    // n = elements, a multiple of In::EPL handled here; each thread converts EPL elements
+    const uint64_t el = ((uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x) * In::EPL;
+    if (el + In::EPL > n) return;
+    float x[In::EPL];
+    In::template load<true>(src + el, x);
+    if constexpr (In::EPL == 4) {
+        uint2v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3])};
+        __builtin_nontemporal_store(o, (uint2v *)(dst + el));
+    } else {
+        uint4v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3]), O::pk(x[4], x[5]), O::pk(x[6], x[7])};
+        __builtin_nontemporal_store(o, (uint4v *)(dst + el));
     }
 }
 

@@ -735,4 +735,160 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_tab(const uint8_t *__restr
     asm volatile("" ::"v"(touch));
 }
 
+// ---- chunk-strided probes for the streaming kernels without LDS --------------------------------
+// widen f16 -> f32: 256 threads, S steps; step j of workgroup 8g+x converts output chunk (g*S+j)*8+x
+// (4 KiB of f32 = 1024 elements, from 2 KiB of f16): 8-byte load, 16-byte store per thread.
+template <int S, bool STRIDED, bool NTL>
+__global__ __launch_bounds__(256) void k_widen_x(const uint2v *__restrict__ src, float *__restrict__ dst, uint64_t n4) {
+    const uint64_t w = blockIdx.x, g = w >> 3;
+    const uint32_t x = (uint32_t)(w & 7);
+    uint2v v[S];
+    uint64_t idx[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const uint64_t chunk = STRIDED ? (g * S + j) * 8 + x : w * S + j;
+        idx[j] = chunk * 256 + threadIdx.x;
+        if (idx[j] < n4) v[j] = NTL ? __builtin_nontemporal_load(src + idx[j]) : src[idx[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        if (idx[j] >= n4) continue;
+        float4v y = {h2f(v[j].x & 0xFFFFu), h2f(v[j].x >> 16), h2f(v[j].y & 0xFFFFu), h2f(v[j].y >> 16)};
+        __builtin_nontemporal_store(y, (float4v *)(dst + 4 * idx[j]));
+    }
+}
+// copy: 16-byte load and store per thread and step, chunks of 4 KiB
+template <int S, bool STRIDED, bool NTL>
+__global__ __launch_bounds__(256) void k_copy_x(const float4v *__restrict__ src, float4v *__restrict__ dst, uint64_t n16) {
+    const uint64_t w = blockIdx.x, g = w >> 3;
+    const uint32_t x = (uint32_t)(w & 7);
+    float4v v[S];
+    uint64_t idx[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        const uint64_t chunk = STRIDED ? (g * S + j) * 8 + x : w * S + j;
+        idx[j] = chunk * 256 + threadIdx.x;
+        if (idx[j] < n16) v[j] = NTL ? __builtin_nontemporal_load(src + idx[j]) : src[idx[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+        if (idx[j] < n16) __builtin_nontemporal_store(v[j], dst + idx[j]);
+}
+
+// ---- workgroup-shape probes for narrow / quantize / permute (THR threads, S steps per thread) ----
+template <class In, class O, int THR, int S>
+__global__ __launch_bounds__(THR) void narrow_x(const typename In::T *__restrict__ src, typename O::T *__restrict__ dst,
+                                                uint64_t n) {
+    const uint64_t base = ((uint64_t)blockIdx.x * THR * S + threadIdx.x) * In::EPL;
+    float x[S][In::EPL];
+    uint64_t el[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        el[i] = base + (uint64_t)i * THR * In::EPL;
+        if (el[i] + In::EPL <= n) In::template load<true>(src + el[i], x[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        if (el[i] + In::EPL > n) continue;
+        if constexpr (In::EPL == 4) {
+            uint2v o = {O::pk(x[i][0], x[i][1]), O::pk(x[i][2], x[i][3])};
+            __builtin_nontemporal_store(o, (uint2v *)(dst + el[i]));
+        } else {
+            uint4v o = {O::pk(x[i][0], x[i][1]), O::pk(x[i][2], x[i][3]), O::pk(x[i][4], x[i][5]), O::pk(x[i][6], x[i][7])};
+            __builtin_nontemporal_store(o, (uint4v *)(dst + el[i]));
+        }
+    }
+}
+
+template <class Q, class In, int THR, int LPT>
+__global__ __launch_bounds__(THR) void quant_x(const typename In::T *__restrict__ src, uint8_t *__restrict__ dst,
+                                               uint64_t nblocks) {
+    constexpr uint32_t ELEMS = THR * In::EPL * LPT, TB = ELEMS / Q::N, TBYTES = TB * Q::BYTES;
+    static_assert(TBYTES % 16 == 0, "tiles leave as whole 16-byte stores");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[TBYTES];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * TB;
+    const uint32_t nblk = rem < TB ? (uint32_t)rem : TB;
+    constexpr uint32_t LANES = Q::N / In::EPL;
+    const typename In::T *in = src + t * ELEMS;
+    float x[LPT][In::EPL];
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)LPT; ++i) {
+        uint32_t el = (i * THR + tid) * In::EPL;
+        if (el / Q::N < nblk) In::template load<true>(in + el, x[i]);
+        else
+            for (uint32_t k = 0; k < In::EPL; ++k) x[i][k] = 0.0f;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)LPT; ++i) {
+        uint32_t el = (i * THR + tid) * In::EPL;
+        uint32_t bt = el / Q::N;
+        Q::template encode<In::EPL>(x[i], tid % LANES, lds + bt * Q::BYTES, bt < nblk);
+    }
+    __syncthreads();
+    const uint32_t nbytes = nblk * Q::BYTES;
+    uint8_t *out = dst + t * TBYTES;
+    for (uint32_t o = tid * 16; o + 16 <= nbytes; o += THR * 16) {
+        const uint4v v = *(const uint4v *)(lds + o);
+        __builtin_nontemporal_store(v, (uint4v *)(out + o));
+    }
+    const uint32_t tail0 = nbytes & ~15u;
+    if (tail0 + tid < nbytes) out[tail0 + tid] = lds[tail0 + tid];
+}
+
+template <int THR, int S>
+__global__ __launch_bounds__(THR) void permute_x(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                 uint64_t row_bytes, uint64_t rows, uint64_t dh) {
+    const uint64_t pieces_per_row = row_bytes / 16;
+    const uint64_t total = pieces_per_row * rows;
+    const uint64_t base = (uint64_t)blockIdx.x * THR * S + threadIdx.x;
+    uint4v v[S];
+    uint64_t off[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const uint64_t p = base + (uint64_t)k * THR;
+        off[k] = ~0ull;
+        if (p >= total) continue;
+        const uint64_t row = p / pieces_per_row, col = p % pieces_per_row;
+        const uint64_t head = row / dh, in_head = row % dh;
+        const uint64_t srow = head * dh + (in_head & 1) * (dh / 2) + (in_head >> 1);
+        v[k] = __builtin_nontemporal_load((const uint4v *)(src + srow * row_bytes + col * 16));
+        off[k] = row * row_bytes + col * 16;
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+        if (off[k] != ~0ull) __builtin_nontemporal_store(v[k], (uint4v *)(dst + off[k]));
+}
+
+template <bool BF16SRC, class O, int THR, int S>
+__global__ __launch_bounds__(THR) void widen_x(const uint2v *__restrict__ src, typename O::T *__restrict__ dst, uint64_t n4) {
+    const uint64_t base = (uint64_t)blockIdx.x * THR * S + threadIdx.x;
+    uint2v v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + (uint64_t)k * THR;
+        if (i < n4) v[k] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + (uint64_t)k * THR;
+        if (i >= n4) continue;
+        float y[4];
+        if (BF16SRC) {
+            y[0] = __uint_as_float(v[k].x << 16); y[1] = __uint_as_float(v[k].x & 0xFFFF0000u);
+            y[2] = __uint_as_float(v[k].y << 16); y[3] = __uint_as_float(v[k].y & 0xFFFF0000u);
+        } else {
+            y[0] = h2f(v[k].x & 0xFFFFu); y[1] = h2f(v[k].x >> 16);
+            y[2] = h2f(v[k].y & 0xFFFFu); y[3] = h2f(v[k].y >> 16);
+        }
+        if constexpr (O::EPL == 4) {
+            O::template store<true>(dst + 4 * i, y);
+        } else {
+            uint2v o = {O::pk(y[0], y[1]), O::pk(y[2], y[3])};
+            __builtin_nontemporal_store(o, (uint2v *)(dst + 4 * i));
+        }
+    }
+}
+
 }  // namespace ggq

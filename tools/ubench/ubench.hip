@@ -31,6 +31,14 @@ using namespace ggq;
         if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); std::exit(2); } \
     } while (0)
 
+__global__ __launch_bounds__(256) void k_init_f32(float *dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        uint64_t z = i * 0x9E3779B97F4A7C15ull;
+        z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        dst[i] = (float)(int32_t)(uint32_t)z * (1.0f / 2147483648.0f);
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_fill(float4v *dst, uint64_t n16) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -170,6 +178,12 @@ int main(int argc, char **argv) {
         for (uint64_t off = 0; off < elems * 2; off += h.size() * 4)
             CK(hipMemcpy(d_in + off, h.data(), std::min<uint64_t>(h.size() * 4, elems * 2 - off), hipMemcpyHostToDevice));
     }
+    // quantizer probes: packed output goes to a buffer of its own; their f32 source (d_out) starts out as
+    // uniform values in (-1, 1), their f16 source is d_in (benign f16 bit patterns)
+    uint8_t *d_q;
+    CK(hipMalloc(&d_q, elems * 2 + 4096));         // packed blocks (<= 1.13 B / element) or 16-bit elements
+    hipLaunchKernelGGL(k_init_f32, dim3(4096), dim3(256), 0, 0, d_out, elems);
+    CK(hipDeviceSynchronize());
     hipStream_t st;
     CK(hipStreamCreate(&st));
     std::vector<Variant> vs;
@@ -511,63 +525,42 @@ int main(int argc, char **argv) {
         unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
         double bytes = (double)elems * ((double)Q::BYTES / Q::N + sizeof(typename In::T));                  \
         vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
-                          hipLaunchKernelGGL((quant_one<Q, In>), dim3(grid), dim3(WG_THREADS), 0, s,        \
-                                             (const typename In::T *)d_out, (uint8_t *)d_in, blocks); }, {}}); \
+                          hipLaunchKernelGGL((quant_one<Q, In>), dim3(grid), dim3(G::THR), 0, s,            \
+                                             sizeof(typename In::T) == 4 ? (const typename In::T *)d_out : (const typename In::T *)d_in, \
+                                             d_q, blocks); }, {}}); \
     }
-#define QNTL(Q, In, L, NTL, NTS, LABEL)                                                                     \
-    {                                                                                                       \
-        typedef QuantGeom<Q, In, L> G;                                                                      \
-        uint64_t blocks = elems / Q::N;                                                                     \
-        unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                           \
-        double bytes = (double)elems * ((double)Q::BYTES / Q::N + sizeof(typename In::T));                  \
-        vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                    \
-                          hipLaunchKernelGGL((quant_one<Q, In, L, NTL, NTS>), dim3(grid), dim3(WG_THREADS), 0, s, \
-                                             (const typename In::T *)d_out, (uint8_t *)d_in, blocks); }, {}}); \
-    }
-    QNTL(EncQ4_0, InF32, 1, false, false, "qv L1 pl pl Q4_0 from f32")
-    QNTL(EncQ4_0, InF32, 1, true, false, "qv L1 nt pl Q4_0 from f32")
-    QNTL(EncQ4_0, InF32, 1, true, true, "qv L1 nt nt Q4_0 from f32")
-    QNTL(EncQ4_0, InF32, 2, true, false, "qv L2 nt pl Q4_0 from f32")
-    QNTL(EncQ4_0, InF32, 2, true, true, "qv L2 nt nt Q4_0 from f32")
-    QNTL(EncQ8_0, InF32, 1, true, false, "qv L1 nt pl Q8_0 from f32")
-    QNTL(EncQ8_0, InF32, 1, true, true, "qv L1 nt nt Q8_0 from f32")
-    QNTL(EncQ8_0, InF32, 2, true, false, "qv L2 nt pl Q8_0 from f32")
-    QNTL(EncQ8_0, InF32, 2, true, true, "qv L2 nt nt Q8_0 from f32")
-    QNTL(EncQ4_1, InF32, 1, true, false, "qv L1 nt pl Q4_1 from f32")
-    QNTL(EncQ4_1, InF32, 2, true, false, "qv L2 nt pl Q4_1 from f32")
-    QNTL(EncQ5_1, InF32, 1, true, false, "qv L1 nt pl Q5_1 from f32")
-    QNTL(EncQ8K, InF32, 1, true, false, "qv L1 nt pl Q8K from f32")
-    QNTL(EncQ8K, InF32, 2, true, false, "qv L2 nt pl Q8K from f32")
-    QNTL(EncQ8_0, InF16, 1, true, false, "qv L1 nt pl Q8_0 from f16")
-    QNTL(EncQ8_0, InF16, 2, true, false, "qv L2 nt pl Q8_0 from f16")
-    QNTL(EncQ4_0, InBF16, 1, true, false, "qv L1 nt pl Q4_0 from bf16")
     {   // the 1-element "blocks": f16 / bf16 widening and narrowing
-        const uint64_t n4 = elems / 4, per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+        const uint64_t n4 = elems / 4, per_wg = (uint64_t)STREAM_THREADS * WidenShape<OutF32>::STEPS;
         const unsigned grid = (unsigned)((n4 + per_wg - 1) / per_wg);
         vs.push_back({"widen f16 -> f32", (double)elems * 6, [=](hipStream_t s) {
-                          hipLaunchKernelGGL((widen_vec<false, OutF32, true>), dim3(grid), dim3(WG_THREADS), 0, s,
+                          hipLaunchKernelGGL((widen_vec<false, OutF32, true>), dim3(grid), dim3(STREAM_THREADS), 0, s,
                                              (const uint2v *)d_in, (float *)d_out, n4); }, {}});
         vs.push_back({"widen bf16 -> f32", (double)elems * 6, [=](hipStream_t s) {
-                          hipLaunchKernelGGL((widen_vec<true, OutF32, true>), dim3(grid), dim3(WG_THREADS), 0, s,
+                          hipLaunchKernelGGL((widen_vec<true, OutF32, true>), dim3(grid), dim3(STREAM_THREADS), 0, s,
                                              (const uint2v *)d_in, (float *)d_out, n4); }, {}});
-        const uint64_t per_wg_n = (uint64_t)WG_THREADS * STORES_PER_THREAD * InF32::EPL;
+        const uint64_t per_wg16 = (uint64_t)STREAM_THREADS * WidenShape<OutBF16>::STEPS;
+        const unsigned grid16 = (unsigned)((n4 + per_wg16 - 1) / per_wg16);
+        vs.push_back({"widen f16 -> bf16", (double)elems * 4, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((widen_vec<false, OutBF16, true>), dim3(grid16), dim3(STREAM_THREADS), 0, s,
+                                             (const uint2v *)d_in, (uint16_t *)d_out, n4); }, {}});
+        const uint64_t per_wg_n = (uint64_t)STREAM_THREADS * InF32::EPL;
         const unsigned gridn = (unsigned)((elems + per_wg_n - 1) / per_wg_n);
         vs.push_back({"narrow f32 -> f16", (double)elems * 6, [=](hipStream_t s) {
-                          hipLaunchKernelGGL((narrow_vec<InF32, OutF16>), dim3(gridn), dim3(WG_THREADS), 0, s,
-                                             (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+                          hipLaunchKernelGGL((narrow_vec<InF32, OutF16>), dim3(gridn), dim3(STREAM_THREADS), 0, s,
+                                             (const float *)d_out, (uint16_t *)d_q, elems); }, {}});
         vs.push_back({"narrow f32 -> bf16", (double)elems * 6, [=](hipStream_t s) {
-                          hipLaunchKernelGGL((narrow_vec<InF32, OutBF16>), dim3(gridn), dim3(WG_THREADS), 0, s,
-                                             (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+                          hipLaunchKernelGGL((narrow_vec<InF32, OutBF16>), dim3(gridn), dim3(STREAM_THREADS), 0, s,
+                                             (const float *)d_out, (uint16_t *)d_q, elems); }, {}});
     }
     {   // row gather of permute_qk over opaque packed rows: [4096 x rows] Q4_K (2304-byte rows) and F16 (8192-byte rows)
         for (uint64_t rb : {2304ull, 8192ull}) {
             const uint64_t rows = (elems * 2 / rb) / 256 * 256, dh = 128;
-            const uint64_t pieces = rb / 16 * rows, per_wg = (uint64_t)WG_THREADS * STORES_PER_THREAD;
+            const uint64_t pieces = rb / 16 * rows, per_wg = STREAM_THREADS;
             const unsigned grid = (unsigned)((pieces + per_wg - 1) / per_wg);
             char label[64];
             std::snprintf(label, sizeof label, "permute_qk rows of %llu bytes", (unsigned long long)rb);
             vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
-                              hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(WG_THREADS), 0, s,
+                              hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(STREAM_THREADS), 0, s,
                                                  (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh, (uint64_t)0); }, {}});
         }
     }
@@ -808,6 +801,123 @@ int main(int argc, char **argv) {
         SHIP(Q4_0, OutF32, "tab ref ship Q4_0 f32")
         SHIP(Q8_0, OutF32, "tab ref ship Q8_0 f32")
         SHIP(Q8_0, OutF16, "tab ref ship Q8_0 f16")
+    }
+    // ---- chunk-strided widen / copy probes
+    {
+        const uint64_t n4 = elems / 4;
+#define WX(S, ST, NTL, LABEL)                                                                               \
+        vs.push_back({LABEL, (double)elems * 6, [=](hipStream_t s) {                                        \
+                          hipLaunchKernelGGL((k_widen_x<S, ST, NTL>), dim3((unsigned)((n4 / 256 / S + 7) / 8 * 8)), dim3(256), 0, s, \
+                                             (const uint2v *)d_in, (float *)d_out, n4); }, {}});
+        WX(1, false, true, "wx widen S1 contig ntl")
+        WX(2, false, true, "wx widen S2 contig ntl")
+        WX(2, true, true, "wx widen S2 strided ntl")
+        WX(4, true, true, "wx widen S4 strided ntl")
+        WX(2, true, false, "wx widen S2 strided plain-ld")
+        WX(4, false, true, "wx widen S4 contig ntl")
+        {
+            const uint64_t per = (uint64_t)STREAM_THREADS * WidenShape<OutF32>::STEPS;
+            const unsigned grid = (unsigned)((n4 + per - 1) / per);
+            vs.push_back({"wx ref ship widen f16 -> f32", (double)elems * 6, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((widen_vec<false, OutF32, true>), dim3(grid), dim3(STREAM_THREADS), 0, s,
+                                                 (const uint2v *)d_in, (float *)d_out, n4); }, {}});
+        }
+        const uint64_t h16 = n16 / 2;        // copy half the buffer onto the other half
+#define CX(S, ST, NTL, LABEL)                                                                               \
+        vs.push_back({LABEL, (double)elems * 4, [=](hipStream_t s) {                                        \
+                          hipLaunchKernelGGL((k_copy_x<S, ST, NTL>), dim3((unsigned)((h16 / 256 / S + 7) / 8 * 8)), dim3(256), 0, s, \
+                                             (const float4v *)d_out, (float4v *)d_out + h16, h16); }, {}});
+        CX(1, false, true, "wx copy S1 contig ntl")
+        CX(2, false, true, "wx copy S2 contig ntl")
+        CX(2, true, true, "wx copy S2 strided ntl")
+        CX(4, true, true, "wx copy S4 strided ntl")
+        CX(2, true, false, "wx copy S2 strided plain-ld")
+    }
+    // ---- workgroup-shape probes: narrow, quantize, permute
+    {
+#define NX(THR, S, LABEL)                                                                                   \
+        vs.push_back({LABEL, (double)elems * 6, [=](hipStream_t s) {                                        \
+                          hipLaunchKernelGGL((narrow_x<InF32, OutF16, THR, S>), dim3((unsigned)(elems / 4 / (THR * S))), dim3(THR), 0, s, \
+                                             (const float *)d_out, (uint16_t *)d_in, elems); }, {}});
+        NX(256, 1, "shape narrow f32->f16 thr256 S1")
+        NX(256, 2, "shape narrow f32->f16 thr256 S2")
+        NX(512, 1, "shape narrow f32->f16 thr512 S1")
+        NX(512, 2, "shape narrow f32->f16 thr512 S2 (=ship)")
+        NX(128, 1, "shape narrow f32->f16 thr128 S1")
+#define QX(Q, THR, LPT, LABEL)                                                                              \
+        {                                                                                                   \
+            const uint64_t blocks = elems / Q::N;                                                           \
+            const uint64_t tb = (uint64_t)THR * 4 * LPT / Q::N;                                             \
+            vs.push_back({LABEL, (double)elems * (4.0 + (double)Q::BYTES / Q::N), [=](hipStream_t s) {      \
+                              hipLaunchKernelGGL((quant_x<Q, InF32, THR, LPT>), dim3((unsigned)((blocks + tb - 1) / tb)), dim3(THR), 0, s, \
+                                                 (const float *)d_out, (uint8_t *)d_in, blocks); }, {}});   \
+        }
+        QX(EncQ8_0, 256, 1, "shape quant Q8_0 thr256 L1")
+        QX(EncQ8_0, 256, 2, "shape quant Q8_0 thr256 L2")
+        QX(EncQ8_0, 512, 1, "shape quant Q8_0 thr512 L1")
+        QX(EncQ8_0, 512, 2, "shape quant Q8_0 thr512 L2 (=ship)")
+        QX(EncQ8_0, 256, 4, "shape quant Q8_0 thr256 L4")
+        QX(EncQ4_0, 256, 1, "shape quant Q4_0 thr256 L1")
+        QX(EncQ4_0, 256, 2, "shape quant Q4_0 thr256 L2")
+        QX(EncQ4_0, 512, 2, "shape quant Q4_0 thr512 L2 (=ship)")
+        QX(EncQ4_1, 256, 2, "shape quant Q4_1 thr256 L2")
+        QX(EncQ4_1, 512, 2, "shape quant Q4_1 thr512 L2 (=ship)")
+        for (uint64_t rb : {2304ull, 8192ull}) {
+            const uint64_t rows = (elems * 2 / rb) / 256 * 256, dh = 128;
+            const uint64_t pieces = rb / 16 * rows;
+            char label[96];
+#define PX(THR, S)                                                                                          \
+            std::snprintf(label, sizeof label, "shape permute rows %llu thr%d S%d", (unsigned long long)rb, THR, S); \
+            vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {                                      \
+                              hipLaunchKernelGGL((permute_x<THR, S>), dim3((unsigned)((pieces + THR * S - 1) / (THR * S))), dim3(THR), 0, s, \
+                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh); }, {}});
+            PX(256, 1) PX(256, 2) PX(512, 1) PX(512, 2)
+        }
+    }
+    // ---- quantizer shape sweep: every encoder, f32 and f16 input
+    {
+#define QXI(Q, IN, INB, THR, LPT, LABEL)                                                                    \
+        {                                                                                                   \
+            const uint64_t blocks = elems / Q::N;                                                           \
+            const uint64_t tb = (uint64_t)THR * IN::EPL * LPT / Q::N;                                       \
+            vs.push_back({LABEL, (double)elems * ((double)INB + (double)Q::BYTES / Q::N), [=](hipStream_t s) { \
+                              hipLaunchKernelGGL((quant_x<Q, IN, THR, LPT>), dim3((unsigned)((blocks + tb - 1) / tb)), dim3(THR), 0, s, \
+                                                 sizeof(typename IN::T) == 4 ? (const typename IN::T *)d_out : (const typename IN::T *)d_in, \
+                                                 d_q, blocks); }, {}}); \
+        }
+#define QSW(Q, NAME)                                                                                        \
+        QXI(Q, InF32, 4, 256, 1, "qsw " NAME " f32 thr256 L1")                                              \
+        QXI(Q, InF32, 4, 256, 2, "qsw " NAME " f32 thr256 L2")                                              \
+        QXI(Q, InF32, 4, 512, 1, "qsw " NAME " f32 thr512 L1")                                              \
+        QXI(Q, InF32, 4, 512, 2, "qsw " NAME " f32 thr512 L2 ship")                                         \
+        QXI(Q, InF16, 2, 256, 1, "qsw " NAME " f16 thr256 L1")                                              \
+        QXI(Q, InF16, 2, 256, 2, "qsw " NAME " f16 thr256 L2")                                              \
+        QXI(Q, InF16, 2, 512, 1, "qsw " NAME " f16 thr512 L1")                                              \
+        QXI(Q, InF16, 2, 512, 2, "qsw " NAME " f16 thr512 L2 ship")
+        QSW(EncQ4_0, "Q4_0") QSW(EncQ4_1, "Q4_1") QSW(EncQ5_0, "Q5_0") QSW(EncQ5_1, "Q5_1") QSW(EncQ8_0, "Q8_0") QSW(EncQ8_1, "Q8_1")
+        QXI(EncQ8K, InF32, 4, 256, 2, "qsw Q8K f32 thr256 L2")
+        QXI(EncQ8K, InF32, 4, 512, 1, "qsw Q8K f32 thr512 L1")
+        QXI(EncQ8K, InF32, 4, 512, 2, "qsw Q8K f32 thr512 L2 ship")
+        QXI(EncQ8K, InF16, 2, 256, 1, "qsw Q8K f16 thr256 L1")
+        QXI(EncQ8K, InF16, 2, 256, 2, "qsw Q8K f16 thr256 L2")
+        QXI(EncQ8K, InF16, 2, 512, 2, "qsw Q8K f16 thr512 L2 ship")
+    }
+    // ---- widen shape sweep
+    {
+        const uint64_t n4 = elems / 4;
+#define WS(THR, S, O, OB, LABEL)                                                                            \
+        vs.push_back({LABEL, (double)elems * (2 + OB), [=](hipStream_t s) {                                 \
+                          hipLaunchKernelGGL((widen_x<false, O, THR, S>), dim3((unsigned)((n4 + THR * S - 1) / (THR * S))), dim3(THR), 0, s, \
+                                             (const uint2v *)d_in, (typename O::T *)d_out, n4); }, {}});
+        WS(128, 1, OutF32, 4, "wsw widen f16->f32 thr128 S1")
+        WS(256, 1, OutF32, 4, "wsw widen f16->f32 thr256 S1")
+        WS(512, 1, OutF32, 4, "wsw widen f16->f32 thr512 S1")
+        WS(512, 2, OutF32, 4, "wsw widen f16->f32 thr512 S2 ship")
+        WS(128, 1, OutBF16, 2, "wsw widen f16->bf16 thr128 S1")
+        WS(256, 1, OutBF16, 2, "wsw widen f16->bf16 thr256 S1")
+        WS(512, 1, OutBF16, 2, "wsw widen f16->bf16 thr512 S1")
+        WS(512, 2, OutBF16, 2, "wsw widen f16->bf16 thr512 S2 ship")
+        WS(256, 2, OutBF16, 2, "wsw widen f16->bf16 thr256 S2")
     }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
