@@ -252,7 +252,7 @@ ggq_status launch_narrow(void *d_dst, const void *d_src, uint64_t n, int cus, hi
     typedef typename In::T TI;
     typedef typename O::T TO;
     const uint64_t nvec = n / In::EPL * In::EPL;
-    const uint64_t per_wg = (uint64_t)STREAM_THREADS * In::EPL;
+    const uint64_t per_wg = (uint64_t)STREAM_THREADS * NARROW_STEPS * In::EPL;
     for (uint64_t i0 = 0; i0 < nvec; i0 += kMaxGrid * per_wg) {
         uint64_t cnt = std::min(kMaxGrid * per_wg, nvec - i0);
         hipLaunchKernelGGL((narrow_vec<In, O>), dim3((uint32_t)((cnt + per_wg - 1) / per_wg)), dim3(STREAM_THREADS),

@@ -243,10 +243,11 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restric
 // from one 8-byte load into one 16-byte store (f32 out; 8 bytes for 2-byte outputs).
 // Requires src 8-byte aligned and dst 16-byte aligned; n4 = elements / 4.
 // Shape of the streaming kernels that need no LDS (this one, narrow_vec, permute_qk_rows): 256 threads
-// and ONE step whose wider side is 16 bytes per thread, so a wave moves 1 KiB and ends -- measured
-// against the decode kernels' 512 x 2 shape on 1 Gi elements: f16 -> f32 6610 GB/s against 6075,
-// f32 -> f16 6640 against 6315, the row gather 6590-6690 against 6070-6120.  Where both sides are 8 bytes
-// per thread (f16 <-> bf16) two steps do better (6530 against 5710).  The decode kernels keep their shape:
+// and one step whose wider side is 16 bytes per thread, so a wave stores 1 KiB and ends -- measured
+// against the decode kernels' 512 x 2 shape on 1 Gi elements, three and thirty launches in a row:
+// f16 -> f32 6610 GB/s against 6080 (both settings), the row gather 6590 / 6300 against 6070 / 6090.
+// Where a thread's store is 8 bytes (f16 <-> bf16 here, narrow_vec) two steps do better (6530 against 5710).
+// The decode kernels keep their shape:
 // their workgroups stage a tile through LDS behind a barrier, and with one store per thread that
 // fixed cost per wave dominates.
 // (Treating f16 as 64-byte blocks and going through the tile kernel measured +2 % without the

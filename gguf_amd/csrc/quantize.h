@@ -402,12 +402,14 @@ struct EncQ8K {
 // Workgroup shape per (encoder, input type): THR threads, each with LPT 16-byte loads in flight.
 // 256 threads beat 512 for every encoder (2-9 %, 1 Gi elements, `ubench ... "qsw "`); one load per thread
 // wins where the packed block is small against its input (Q4_0 and Q5_0 from f32: 6450 / 6360 GB/s against
-// 6020 / 6190 with the earlier 512 x 2; Q5_0 and Q5_1 from 16-bit input), two loads elsewhere.
+// 6020 / 6190 with the earlier 512 x 2; Q4_1, Q5_0 and Q5_1 from 16-bit input), two loads elsewhere.
 template <class Q, class In> struct QuantShape { static constexpr uint32_t THR = 256, LPT = 2; };
 template <> struct QuantShape<EncQ4_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_0, InF16> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_0, InBF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ4_1, InF16> { static constexpr uint32_t THR = 256, LPT = 1; };
+template <> struct QuantShape<EncQ4_1, InBF16> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_1, InF16> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_1, InBF16> { static constexpr uint32_t THR = 256, LPT = 1; };
 
@@ -462,21 +464,32 @@ __global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const type
 }
 
 // ---- f32 / f16 / bf16 -> f16 / bf16 (the 1-element "blocks", half.rs:10-17, 26-33) ----
-// One step per thread (see widen_vec for the measurements behind the shape).
+// 256 threads, two steps per thread: 6510 GB/s for f32 -> f16 on 1 Gi elements whether a launch runs behind
+// another kernel or behind thirty of its own; one step per thread measured 6550-6640 in the first setting but
+// 6230 in the second, the earlier 512 threads x 2 steps 6300 in both.
+constexpr uint32_t NARROW_STEPS = 2;
 template <class In, class O>
 __global__ __launch_bounds__(STREAM_THREADS) void narrow_vec(const typename In::T *__restrict__ src,
                                                              typename O::T *__restrict__ dst, uint64_t n) {
-    // n = elements, a multiple of In::EPL handled here; each thread converts EPL elements
-    const uint64_t el = ((uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x) * In::EPL;
-    if (el + In::EPL > n) return;
-    float x[In::EPL];
-    In::template load<true>(src + el, x);
-    if constexpr (In::EPL == 4) {
-        uint2v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3])};
-        __builtin_nontemporal_store(o, (uint2v *)(dst + el));
-    } else {
-        uint4v o = {O::pk(x[0], x[1]), O::pk(x[2], x[3]), O::pk(x[4], x[5]), O::pk(x[6], x[7])};
-        __builtin_nontemporal_store(o, (uint4v *)(dst + el));
+    // n = elements, a multiple of In::EPL handled here; each thread converts EPL elements per step
+    const uint64_t base = ((uint64_t)blockIdx.x * STREAM_THREADS * NARROW_STEPS + threadIdx.x) * In::EPL;
+    float x[NARROW_STEPS][In::EPL];
+#pragma unroll
+    for (uint32_t i = 0; i < NARROW_STEPS; ++i) {
+        const uint64_t el = base + (uint64_t)i * STREAM_THREADS * In::EPL;
+        if (el + In::EPL <= n) In::template load<true>(src + el, x[i]);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < NARROW_STEPS; ++i) {
+        const uint64_t el = base + (uint64_t)i * STREAM_THREADS * In::EPL;
+        if (el + In::EPL > n) continue;
+        if constexpr (In::EPL == 4) {
+            uint2v o = {O::pk(x[i][0], x[i][1]), O::pk(x[i][2], x[i][3])};
+            __builtin_nontemporal_store(o, (uint2v *)(dst + el));
+        } else {
+            uint4v o = {O::pk(x[i][0], x[i][1]), O::pk(x[i][2], x[i][3]), O::pk(x[i][4], x[i][5]), O::pk(x[i][6], x[i][7])};
+            __builtin_nontemporal_store(o, (uint4v *)(dst + el));
+        }
     }
 }
 

@@ -12,10 +12,17 @@ import gguf_amd as g  # noqa: E402
 from gguf_amd import rearrange as R  # noqa: E402
 from gguf_amd.quants import GGmlType as T  # noqa: E402
 
+import time  # noqa: E402
+
 n = 1 << 30
-reps = 12
+reps = 30
 x = torch.randn(n, device="cuda") * 0.02
 bytes_per_launch = {}
+# the GPU reaches its steady clocks only after tens of milliseconds of load: keep it busy first
+t_end = time.perf_counter() + 0.3
+while time.perf_counter() < t_end:
+    x.mul_(1.0)
+    torch.cuda.synchronize()
 
 for ty in (T.Q4_0, T.Q8_0):
     dst = torch.empty(n // 32 * g.block_bytes(ty), dtype=torch.uint8, device="cuda")

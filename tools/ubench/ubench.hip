@@ -543,7 +543,7 @@ int main(int argc, char **argv) {
         vs.push_back({"widen f16 -> bf16", (double)elems * 4, [=](hipStream_t s) {
                           hipLaunchKernelGGL((widen_vec<false, OutBF16, true>), dim3(grid16), dim3(STREAM_THREADS), 0, s,
                                              (const uint2v *)d_in, (uint16_t *)d_out, n4); }, {}});
-        const uint64_t per_wg_n = (uint64_t)STREAM_THREADS * InF32::EPL;
+        const uint64_t per_wg_n = (uint64_t)STREAM_THREADS * NARROW_STEPS * InF32::EPL;
         const unsigned gridn = (unsigned)((elems + per_wg_n - 1) / per_wg_n);
         vs.push_back({"narrow f32 -> f16", (double)elems * 6, [=](hipStream_t s) {
                           hipLaunchKernelGGL((narrow_vec<InF32, OutF16>), dim3(gridn), dim3(STREAM_THREADS), 0, s,
@@ -1032,7 +1032,9 @@ int main(int argc, char **argv) {
     CK(hipStreamSynchronize(st));
     // every round visits the variants in a fresh random order (so no variant always
     // runs behind the same predecessor); one sample = REP back-to-back launches
-    const int REP = 3;
+    // UBENCH_REP (environment): launches per sample; a long run of one kernel behind itself can behave
+    // differently from three launches behind some other variant
+    const int REP = std::getenv("UBENCH_REP") ? std::max(1, std::atoi(std::getenv("UBENCH_REP"))) : 3;
     std::vector<size_t> order(vs.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     uint64_t rng = 0x2545F4914F6CDD1Dull;
