@@ -190,6 +190,31 @@ def cpu_baseline(items, out_ty_name, budget_s, min_elems=1_000_000_000):
 # --------------------------------------------------------------------------------------
 # GPU legs
 # --------------------------------------------------------------------------------------
+def bind_near_gpu(index):
+    """N > 1: run this rank on the CPUs of the NUMA node its GPU hangs off, before any page-locked memory is
+    allocated (first touch places it there), so that the streamed leg's H2D reads do not cross sockets.
+    Best effort: returns a note for the JSON line, changes nothing when the topology cannot be read."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return f"gpu {bdf}: no NUMA node reported"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        mine = cpus & os.sched_getaffinity(0)
+        if not mine:
+            return f"gpu {bdf}: node {node} has none of this process's CPUs"
+        os.sched_setaffinity(0, mine)
+        return f"gpu {bdf}: bound to NUMA node {node} ({len(mine)} CPUs)"
+    except Exception as e:
+        return f"not bound ({type(e).__name__})"
+
+
+
 class Share:
     """One rank's pieces of the job: packed blocks and decoded output resident in HBM, one launch
     plan per block type (largest first)."""
@@ -365,9 +390,11 @@ def main():
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        numa_note = bind_near_gpu(local)
 
     def fence():
         torch.cuda.synchronize()
@@ -430,6 +457,8 @@ def main():
                         f"{staging >> 20} MiB device staging in 2 slots, copy and decode on 2 streams; decoded tensors stay in HBM",
                 "verified": None if args.no_verify else {"blocks": s_blocks, "ok": s_ok},
             }
+            if numa_note:
+                streamed["rank0_cpu_binding"] = numa_note
         except Exception as e:          # never lose the main line to the secondary leg
             streamed = {"error": f"{type(e).__name__}: {e}"}
         if world > 1:
