@@ -402,7 +402,7 @@ struct EncQ8K {
 // Workgroup shape per (encoder, input type): THR threads, each with LPT 16-byte loads in flight.
 // 256 threads beat 512 for every encoder (2-9 %, 1 Gi elements, `ubench ... "qsw "`); one load per thread
 // wins where the packed block is small against its input (Q4_0 and Q5_0 from f32: 6450 / 6360 GB/s against
-// 6020 / 6190 with the earlier 512 x 2; Q4_1, Q5_0 and Q5_1 from 16-bit input), two loads elsewhere.
+// 6020 / 6190 with 512 threads x 2 loads; Q4_1, Q5_0 and Q5_1 from 16-bit input), two loads elsewhere.
 template <class Q, class In> struct QuantShape { static constexpr uint32_t THR = 256, LPT = 2; };
 template <> struct QuantShape<EncQ4_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
 template <> struct QuantShape<EncQ5_0, InF32> { static constexpr uint32_t THR = 256, LPT = 1; };
@@ -466,7 +466,7 @@ __global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const type
 // ---- f32 / f16 / bf16 -> f16 / bf16 (the 1-element "blocks", half.rs:10-17, 26-33) ----
 // 256 threads, two steps per thread: 6510 GB/s for f32 -> f16 on 1 Gi elements whether a launch runs behind
 // another kernel or behind thirty of its own; one step per thread measured 6550-6640 in the first setting but
-// 6230 in the second, the earlier 512 threads x 2 steps 6300 in both.
+// 6230 in the second, 512 threads x 2 steps 6300 in both.
 constexpr uint32_t NARROW_STEPS = 2;
 template <class In, class O>
 __global__ __launch_bounds__(STREAM_THREADS) void narrow_vec(const typename In::T *__restrict__ src,
