@@ -919,6 +919,41 @@ int main(int argc, char **argv) {
         WS(512, 2, OutBF16, 2, "wsw widen f16->bf16 thr512 S2 ship")
         WS(256, 2, OutBF16, 2, "wsw widen f16->bf16 thr256 S2")
     }
+    // ---- workgroup shape of the decode kernel, 16-bit and f32 output, burst prefetch kept at the same BYTES
+    {
+#define SDEQ(F, O, THR, S, PB, LB, LABEL)                                                                   \
+        {                                                                                                   \
+            typedef SGeom<F, O, THR, S> G;                                                                  \
+            const uint64_t blocks = elems / F::N;                                                           \
+            const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                 \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));         \
+            const uint32_t P = (uint32_t)((PB) / G::TBYTES), L = (uint32_t)((LB) / G::TBYTES);              \
+            vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                \
+                              hipLaunchKernelGGL((deq_one_s<F, O, THR, S>), dim3(grid), dim3(THR), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}}); \
+        }
+        // shipped single-tensor schedule for Q4K f16: {768, 1280} tiles of 4608 bytes; f32: {768, 1280} tiles of 2304 bytes
+        const uint64_t PB16 = 768ull * 4608, LB16 = 1280ull * 4608, PB32 = 768ull * 2304, LB32 = 1280ull * 2304;
+        SDEQ(Q4K, OutF16, 512, 2, PB16, LB16, "sdeq Q4K f16 thr512 S2 (=ship)")
+        SDEQ(Q4K, OutF16, 256, 2, PB16, LB16, "sdeq Q4K f16 thr256 S2")
+        SDEQ(Q4K, OutF16, 512, 1, PB16, LB16, "sdeq Q4K f16 thr512 S1")
+        SDEQ(Q4K, OutF16, 256, 1, PB16, LB16, "sdeq Q4K f16 thr256 S1")
+        SDEQ(Q4K, OutF16, 256, 4, PB16, LB16, "sdeq Q4K f16 thr256 S4")
+        SDEQ(Q4K, OutF16, 128, 2, PB16, LB16, "sdeq Q4K f16 thr128 S2")
+        SDEQ(Q4K, OutF16, 1024, 1, PB16, LB16, "sdeq Q4K f16 thr1024 S1")
+        SDEQ(Q4K, OutF32, 512, 2, PB32, LB32, "sdeq Q4K f32 thr512 S2 (=ship)")
+        SDEQ(Q4K, OutF32, 256, 2, PB32, LB32, "sdeq Q4K f32 thr256 S2")
+        SDEQ(Q4K, OutF32, 512, 1, PB32, LB32, "sdeq Q4K f32 thr512 S1")
+        SDEQ(Q4K, OutF32, 256, 1, PB32, LB32, "sdeq Q4K f32 thr256 S1")
+        SDEQ(Q4K, OutF32, 1024, 1, PB32, LB32, "sdeq Q4K f32 thr1024 S1")
+        SDEQ(Q4K, OutF32, 128, 2, PB32, LB32, "sdeq Q4K f32 thr128 S2")
+        SDEQ(Q6K, OutF16, 512, 2, 0, 0, "sdeq Q6K f16 thr512 S2 nopf (=ship)")
+        SDEQ(Q6K, OutF16, 256, 2, 0, 0, "sdeq Q6K f16 thr256 S2 nopf")
+        SDEQ(Q6K, OutF16, 512, 1, 0, 0, "sdeq Q6K f16 thr512 S1 nopf")
+        SDEQ(Q8_0, OutF16, 512, 2, 0, 0, "sdeq Q8_0 f16 thr512 S2 nopf (=ship)")
+        SDEQ(Q8_0, OutF16, 256, 2, 0, 0, "sdeq Q8_0 f16 thr256 S2 nopf")
+        SDEQ(Q8_0, OutF16, 512, 1, 0, 0, "sdeq Q8_0 f16 thr512 S1 nopf")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
