@@ -281,3 +281,35 @@ def test_offset_beyond_data_is_not_backed():
     buf = _with_data(_s(b"t") + struct.pack("<IQIQ", 1, 32, 1, 4096 - 64))      # exactly fits
     with G.GGuf.from_bytes(buf) as g:
         assert g.tensors[0].ptr is not None and bytes(g.tensors[0].bytes()[-1:]) == b"\xff"
+
+
+def test_extreme_tensor_records_never_yield_bad_pointers():
+    """Tensor records drawn from extreme dimension / offset / type values, with a data region present: the parse
+    either fails with a reader error or hands out pointers whose whole range lies inside the data region."""
+    from hypothesis import given, settings, strategies as st
+    dims = st.sampled_from([0, 1, 31, 32, 256, 4096, 2 ** 31, 2 ** 32, 2 ** 33, 2 ** 62, 2 ** 63, 2 ** 64 - 1])
+    offs = st.sampled_from([0, 32, 64, 4096 - 64, 4096, 2 ** 32, 2 ** 63, 2 ** 64 - 4096, 2 ** 64 - 63, 2 ** 64 - 1])
+    tys = st.sampled_from([0, 1, 2, 8, 12, 14, 20, 24, 28, 30, 31, 77, 2 ** 32 - 1])
+
+    @settings(max_examples=600, deadline=None, derandomize=True)
+    @given(st.lists(st.tuples(st.lists(dims, min_size=0, max_size=5), tys, offs), min_size=1, max_size=3))
+    def run(records):
+        head = _hdr(len(records), 0)
+        for i, (shape, ty, off) in enumerate(records):
+            head += _s(b"t%d" % i) + struct.pack("<I", len(shape)) + b"".join(struct.pack("<Q", d) for d in shape)
+            head += struct.pack("<IQ", ty, off)
+        head += b"\0" * ((32 - len(head) % 32) % 32)
+        buf = np.frombuffer(head + bytes(4096), dtype=np.uint8).copy()
+        try:
+            with G.GGuf.from_bytes(buf) as g:
+                assert g.data_avail == 4096
+                for t in g.tensors:
+                    if t.ptr:
+                        assert t.nbytes > 0 and t.offset + t.nbytes <= 4096
+                        b = t.bytes()
+                        assert b[0] == 0 and b[-1] == 0          # readable end to end
+                        assert t.ptr == buf.ctypes.data + g.data_offset + t.offset
+        except G.GGufError as e:
+            assert e.kind in ("Indivisible", "TensorRange", "Eos")
+
+    run()
