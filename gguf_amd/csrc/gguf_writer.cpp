@@ -110,8 +110,10 @@ ggq_gguf_error tensor_bytes(uint32_t ty, const uint64_t *shape, uint32_t ndim, u
         return GGQ_GGUF_OK;
     }
     if (shape[0] % be != 0) return GGQ_GGUF_INDIVISIBLE;
-    uint64_t n = shape[0] / be * bb;
-    for (uint32_t i = 1; i < ndim; ++i) n *= shape[i];
+    uint64_t n = 0;
+    bool wraps = __builtin_mul_overflow(shape[0] / be, bb, &n);
+    for (uint32_t i = 1; i < ndim; ++i) wraps |= __builtin_mul_overflow(n, shape[i], &n);
+    if (wraps) return GGQ_GGUF_TENSOR_RANGE;      // the size does not fit 64 bits
     *out = n;
     return GGQ_GGUF_OK;
 }

@@ -193,3 +193,14 @@ def test_plan_shards_edges():
     assert G.plan_shards(32, [], t, max_tensor_count=1) == ([0, 1], 2)
     # a first tensor that is already over the size limit leaves the first shard empty (as the reference does)
     assert G.plan_shards(32, [], t, max_file_size=1) == ([1, 2], 3)
+
+
+def test_sizes_that_overflow_are_refused():
+    w = G.GGufFileWriter(None)
+    with pytest.raises(G.GGufError) as e:
+        w.write_tensor("t", 0, [2 ** 33, 2 ** 33])
+    assert e.value.kind == "TensorRange"
+    with pytest.raises(G.GGufError) as e:
+        w.write_tensor("t", 12, [100, 4])
+    assert e.value.kind == "Indivisible"
+    w.close()
