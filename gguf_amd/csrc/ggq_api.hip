@@ -891,30 +891,51 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
         }
         if (std::find(types.begin(), types.end(), ty) == types.end()) types.push_back(ty);
     }
-    // one TileRef per tile, tensors of one type consecutive (caller's order inside a type)
-    std::vector<TileRef> table;
+    // One TileRef per tile, tensors of one type consecutive (caller's order inside a type).  The host only
+    // writes one descriptor per tensor; a small kernel per group expands them into the table.
+    std::vector<TensorDesc> descs;
+    struct Span { size_t desc0, ndesc; };
+    std::vector<Span> spans;
     const uint64_t ob = out_bytes(out_ty);
+    uint64_t total_tiles = 0;
     for (uint32_t ty : types) {
         const TypeInfo *ti = type_info(ty);
         const HostGeom hg = host_geom(ti, out_ty);
-        ggq_batch::Group g{ty, table.size(), 0};
+        ggq_batch::Group g{ty, total_tiles, 0};
+        Span sp{descs.size(), 0};
         for (size_t i = 0; i < count; ++i) {
             if (tensors[i].ggml_type != ty || tensors[i].blocks == 0) continue;
             const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
             if (src >> 48) { ggq_batch_destroy(b); return GGQ_INVALID; }
-            const uint64_t nt = (tensors[i].blocks + hg.blocks - 1) / hg.blocks;
-            for (uint64_t t = 0; t < nt; ++t) {
-                uint64_t nblk = std::min<uint64_t>(hg.blocks, tensors[i].blocks - t * hg.blocks);
-                table.push_back({(src + t * hg.bytes) | (nblk << 48), dst + t * hg.elems * ob});
-            }
+            descs.push_back({src, dst, tensors[i].blocks, g.ntiles});
+            g.ntiles += (tensors[i].blocks + hg.blocks - 1) / hg.blocks;
+            ++sp.ndesc;
         }
-        g.ntiles = table.size() - g.first;
+        total_tiles += g.ntiles;
         b->groups.push_back(g);
+        spans.push_back(sp);
     }
-    if (!table.empty()) {
-        if (!hip_ok(hipMalloc((void **)&b->d_table, table.size() * sizeof(TileRef)), "hipMalloc") ||
-            !hip_ok(hipMemcpy(b->d_table, table.data(), table.size() * sizeof(TileRef), hipMemcpyHostToDevice),
-                    "hipMemcpy")) {
+    if (total_tiles) {
+        TensorDesc *d_desc = nullptr;
+        bool ok = hip_ok(hipMalloc((void **)&b->d_table, total_tiles * sizeof(TileRef)), "hipMalloc") &&
+                  hip_ok(hipMalloc((void **)&d_desc, descs.size() * sizeof(TensorDesc)), "hipMalloc") &&
+                  hip_ok(hipMemcpy(d_desc, descs.data(), descs.size() * sizeof(TensorDesc), hipMemcpyHostToDevice),
+                         "hipMemcpy");
+        for (size_t k = 0; ok && k < b->groups.size(); ++k) {
+            const auto &g = b->groups[k];
+            const HostGeom hg = host_geom(type_info(g.ty), out_ty);
+            for (uint64_t t0 = 0; t0 < g.ntiles; t0 += kMaxGrid * 256) {
+                const uint64_t end = std::min(g.ntiles, t0 + kMaxGrid * 256);
+                hipLaunchKernelGGL(build_tile_table, dim3((uint32_t)((end - t0 + 255) / 256)), dim3(256), 0,
+                                   (hipStream_t)0, b->d_table + g.first, d_desc + spans[k].desc0,
+                                   (uint32_t)spans[k].ndesc, t0, end, (uint32_t)hg.blocks, (uint32_t)hg.bytes,
+                                   (uint32_t)(hg.elems * ob));
+            }
+            ok = hip_ok(hipGetLastError(), "build_tile_table");
+        }
+        ok = ok && hip_ok(hipStreamSynchronize((hipStream_t)0), "hipStreamSynchronize");
+        if (d_desc) (void)hipFree(d_desc);
+        if (!ok) {
             ggq_batch_destroy(b);
             return GGQ_DEVICE;
         }

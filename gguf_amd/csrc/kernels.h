@@ -115,6 +115,34 @@ struct TileRef {
     uint64_t dst;        // address of the tile's first output element (16-byte aligned)
 };
 
+// One tensor of a batch group, as the host describes it: the tile table is expanded from these on the
+// device (a 7B-parameter model is ~1.6 M tiles = 26 MB of records, which the host would spend longer
+// writing and copying than the decode takes).
+struct TensorDesc {
+    uint64_t src, dst;      // first block, first output element
+    uint64_t blocks;        // blocks in the tensor
+    uint64_t first_tile;    // index of the tensor's first tile in the group (ascending over the array)
+};
+
+// table[i] for tiles i in [tile0, tile_end) of the group; one thread per tile, the tensor found by binary search
+__global__ __launch_bounds__(256) void build_tile_table(TileRef *__restrict__ table, const TensorDesc *__restrict__ desc,
+                                                        uint32_t ntensors, uint64_t tile0, uint64_t tile_end,
+                                                        uint32_t tile_blocks, uint32_t tile_bytes, uint32_t tile_out_bytes) {
+    const uint64_t tile = tile0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tile >= tile_end) return;
+    uint32_t lo = 0, hi = ntensors - 1;            // largest k with desc[k].first_tile <= tile
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (desc[mid].first_tile <= tile) lo = mid;
+        else hi = mid - 1;
+    }
+    const TensorDesc d = desc[lo];
+    const uint64_t t = tile - d.first_tile;
+    const uint64_t left = d.blocks - t * tile_blocks;
+    const uint64_t nblk = left < tile_blocks ? left : tile_blocks;
+    table[tile] = TileRef{(d.src + t * tile_bytes) | (nblk << 48), d.dst + t * tile_out_bytes};
+}
+
 // Which 128-byte line, if any, this thread touches for the burst prefetch.
 // Workgroups are numbered t = 0, 1, ... in dispatch order; the first
 // NB = ceil(period / TPW) workgroups of every `period` are on prefetch duty: together

@@ -52,6 +52,15 @@ for (_, _, d), p in zip(tensors, packed):
     assert same_bits(d.cpu().numpy(), o.dequantize(12, p, threads=4)), "batch"
 b.close()
 
+# a group of more than 3 * 256 tiles: the tile table itself is built by several launches
+p = synth.random_blocks(12, 16 * 1700 + 3, 79)
+d = t.empty((16 * 1700 + 3) * 256, dtype=t.float32, device="cuda")
+b = g.Batch([(12, t.from_numpy(p).cuda(), d)])
+b.run()
+t.cuda.synchronize()
+assert same_bits(d.cpu().numpy(), o.dequantize(12, p, threads=4)), "batch, table built in pieces"
+b.close()
+
 # widen (F16 / BF16 sources) and narrow / quantize
 for ty in (1, 30):
     nel = 10 * 4096 + 5
