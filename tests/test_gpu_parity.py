@@ -352,3 +352,32 @@ def test_full_size_properties(torch_cuda, oracle):
         want = oracle.dequantize(ty, sample, threads=8)
         got = dst.view(blocks, n)[idx].cpu().numpy().reshape(-1)
         assert same_bits(got, want)
+
+
+def test_batch_plan_replayed_from_a_graph(torch_cuda, oracle):
+    """A launch plan is plain kernel launches on the caller's stream, so it can be captured into a HIP graph;
+    replays, with the inputs rewritten and eager work in between, must each give the oracle's bits."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    specs = [(12, 16 * 40 + 3), (14, 300), (2, 5000), (20, 999), (1, 70001)]
+    srcs = [t.empty(b * g.block_bytes(ty), dtype=t.uint8, device="cuda") for ty, b in specs]
+    dsts = [t.empty(b * g.block_elems(ty), dtype=t.float16, device="cuda") for ty, b in specs]
+    plan = g.Batch([(ty, s, d) for (ty, _), s, d in zip(specs, srcs, dsts)], g.GGmlType.F16)
+    graph = t.cuda.CUDAGraph()
+    with t.cuda.graph(graph, capture_error_mode="thread_local"):
+        plan.run(t.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        packed = [synth.random_blocks(ty, b, 7000 + 10 * rep + i) for i, (ty, b) in enumerate(specs)]
+        for s, p in zip(srcs, packed):
+            s.copy_(t.from_numpy(p))
+        for d in dsts:
+            d.fill_(-1.0)
+        t.cuda.synchronize()
+        graph.replay()
+        t.cuda.synchronize()
+        for (ty, _), d, p in zip(specs, dsts, packed):
+            want = oracle.dequantize(ty, p, oracle.F16, threads=4)
+            got = d.view(t.int16).cpu().numpy().view(np.uint16)
+            assert same_bits16(got, want, "f16"), (rep, ty, first_diff(got, want))
+    plan.close()
