@@ -71,6 +71,7 @@ SYMBOLS = {
     "ggq_ctx_create": (_int, [_int, _sz, ctypes.POINTER(_vp)]),
     "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),
     "ggq_upload_async": (_int, [_vp, _vp, _vp, _sz]),
+    "ggq_ctx_fence": (_int, [_vp, _vp]),
     "ggq_dequantize_noalloc": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
     "ggq_sync": (_int, [_vp]),
     "ggq_ctx_destroy": (None, [_vp]),

@@ -552,11 +552,11 @@ class _Producer:
                                 srcs.append(d)
                                 n = c.src.arr.size // block_bytes(c.from_ty) * block_elems(c.from_ty)
                                 outs.append(torch.empty(n, dtype=_torch_dtype(c.to_ty), device=dev))
-                            ctx.sync()
                             by_out = {}
                             for (name, t), sd, od in zip(unit, srcs, outs):
                                 by_out.setdefault(t.data.to_ty, []).append((t.data.from_ty, sd, od))
-                            plans = [Batch(v, k) for k, v in by_out.items()]
+                            plans = [Batch(v, k) for k, v in by_out.items()]     # built while the last copies fly
+                            ctx.sync()
                             for p in plans:
                                 p.run(stream.cuda_stream)
                                 self.launches += p.launches

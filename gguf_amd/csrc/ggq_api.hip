@@ -357,11 +357,14 @@ struct ggq_ctx {
     size_t out_cap = 0;     // bytes per slot, decoded output (0 for a decode-only context)
     hipStream_t stream[SLOTS] = {};
     hipEvent_t done[SLOTS] = {};
+    hipEvent_t fence[SLOTS] = {};   // ggq_ctx_fence: one per stream, re-recorded by every fence
     uint8_t *h_in[SLOTS] = {};
     uint8_t *d_in[SLOTS] = {};
     uint8_t *h_out[SLOTS] = {};
     uint8_t *d_out[SLOTS] = {};
     bool busy[SLOTS] = {};
+    int next = 0;           // slot the next chunk takes: slots alternate ACROSS calls too, so that a call's
+                            // staging copy overlaps the DMA the call before it started
 };
 
 namespace {
@@ -477,6 +480,7 @@ void ctx_free(ggq_ctx *c) {
         if (c->d_in[s]) (void)hipFree(c->d_in[s]);
         if (c->d_out[s]) (void)hipFree(c->d_out[s]);
         if (c->done[s]) (void)hipEventDestroy(c->done[s]);
+        if (c->fence[s]) (void)hipEventDestroy(c->fence[s]);
         if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     }
     delete c;
@@ -501,6 +505,7 @@ ggq_status ctx_make(int device, size_t in_cap, size_t out_cap, ggq_ctx **out) {
     for (int s = 0; s < ggq_ctx::SLOTS && ok; ++s) {
         ok = ok && hip_ok(hipStreamCreateWithFlags(&c->stream[s], hipStreamNonBlocking), "hipStreamCreate");
         ok = ok && hip_ok(hipEventCreateWithFlags(&c->done[s], hipEventDisableTiming), "hipEventCreate");
+        ok = ok && hip_ok(hipEventCreateWithFlags(&c->fence[s], hipEventDisableTiming), "hipEventCreate");
         ok = ok && hip_ok(hipHostMalloc((void **)&c->h_in[s], in_cap + 32, hipHostMallocDefault), "hipHostMalloc");
         ok = ok && hip_ok(hipMalloc((void **)&c->d_in[s], in_cap + 32), "hipMalloc");
         if (out_cap) {
@@ -1017,9 +1022,7 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
         if (hipPointerGetAttributes(&attr, h_src) == hipSuccess) src_pinned = attr.type == hipMemoryTypeHost;
         else (void)hipGetLastError();      // ordinary pageable memory is "not found", not an error
     }
-    // find the slot that was used least recently: slots alternate, so continue
-    // from the first idle one
-    int slot = c->busy[0] && !c->busy[1] ? 1 : 0;
+    int slot = c->next;
     for (size_t done = 0; done < src_blocks && rc == GGQ_OK;) {
         size_t nb = std::min(chunk_blocks, src_blocks - done);
         if (c->busy[slot]) {
@@ -1045,6 +1048,7 @@ ggq_status ggq_dequantize_async(ggq_ctx *c, uint32_t ty, uint32_t out_ty, void *
         done += nb;
         slot ^= 1;
     }
+    c->next = slot;
     (void)hipSetDevice(prev);
     return rc;
 }
@@ -1065,7 +1069,7 @@ ggq_status ggq_upload_async(ggq_ctx *c, void *d_dst, const void *h_src, size_t b
         else (void)hipGetLastError();
     }
     ggq_status rc = GGQ_OK;
-    int slot = c->busy[0] && !c->busy[1] ? 1 : 0;
+    int slot = c->next;
     for (size_t done = 0; done < bytes && rc == GGQ_OK;) {
         const size_t n = std::min(c->in_cap, bytes - done);
         hipStream_t q = c->stream[slot];
@@ -1086,6 +1090,7 @@ ggq_status ggq_upload_async(ggq_ctx *c, void *d_dst, const void *h_src, size_t b
         done += n;
         slot ^= 1;
     }
+    c->next = slot;
     (void)hipSetDevice(prev);
     return rc;
 }
@@ -1121,6 +1126,21 @@ ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, siz
     hipStream_t q = (hipStream_t)hip_stream;
     HIP_TRY(hipMemcpyAsync(nd.ptr, h_src, src_blocks * ti->bytes, hipMemcpyHostToDevice, q));
     return launch_out(ty, out_ty, d_dst, nd.ptr, src_blocks, nd.cus, q);
+}
+
+ggq_status ggq_ctx_fence(ggq_ctx *c, void *hip_stream) {
+    if (!c) return GGQ_INVALID;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(c->device));
+    ggq_status rc = GGQ_OK;
+    for (int s = 0; s < ggq_ctx::SLOTS && rc == GGQ_OK; ++s) {
+        if (!hip_ok(hipEventRecord(c->fence[s], c->stream[s]), "hipEventRecord") ||
+            !hip_ok(hipStreamWaitEvent((hipStream_t)hip_stream, c->fence[s], 0), "hipStreamWaitEvent"))
+            rc = GGQ_DEVICE;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 ggq_status ggq_sync(ggq_ctx *c) {

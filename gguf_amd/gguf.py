@@ -6,6 +6,7 @@ time (xtask/src/utils/operator/cast.rs:73-90).
 """
 import ctypes
 import struct
+import threading
 
 import numpy as np
 
@@ -40,9 +41,10 @@ def _check(code):
 
 class TensorInfo:
     """GGufTensorInfo (ggus/src/tensor.rs:255-290) plus where its bytes are."""
-    __slots__ = ("name", "ty", "shape", "offset", "nbytes", "ptr")
+    __slots__ = ("name", "ty", "shape", "offset", "nbytes", "ptr", "_region")
 
-    def __init__(self, t):
+    def __init__(self, t, region=None):
+        self._region = region              # () -> uint8 view of the file's whole data region, or None
         self.name = ctypes.string_at(t.name, t.name_len).decode()
         self.ty = t.ggml_type
         self.shape = tuple(t.shape[i] for i in range(min(t.ndim, 4)))
@@ -54,6 +56,8 @@ class TensorInfo:
         """Zero-copy uint8 view of the packed data (valid while the GGuf is open)."""
         if not self.ptr:
             raise ValueError(f"{self.name}: the file holds no data for this tensor")
+        if self._region is not None:       # a slice of one cached view: building a view per tensor costs ~50 us
+            return self._region()[self.offset:self.offset + self.nbytes]
         return np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(self.nbytes,))
 
     @property
@@ -101,11 +105,23 @@ class GGuf:
         self.data_len = info.data_len
         self.data_avail = info.data_avail
         self.tensors = []
+        self._data_view = None
+        self._data_base = None
         t = _lib.ggq_gguf_tensor()
         for i in range(info.tensor_count):
             _check(lib.ggq_gguf_tensor_at(h, i, ctypes.byref(t)))
-            self.tensors.append(TensorInfo(t))
+            ti = TensorInfo(t, self._region)
+            if ti.ptr and self._data_base is None:
+                self._data_base = ti.ptr - ti.offset
+            self.tensors.append(ti)
         self._kv_count = info.kv_count
+
+    def _region(self):
+        """uint8 view of the whole data region (built once; tensors slice it)."""
+        if self._data_view is None:
+            self._data_view = np.ctypeslib.as_array(ctypes.cast(self._data_base, ctypes.POINTER(ctypes.c_uint8)),
+                                                    shape=(self.data_avail,))
+        return self._data_view
 
     @classmethod
     def from_bytes(cls, buf):
@@ -137,10 +153,11 @@ class GGuf:
     def tensor(self, name):
         t = _lib.ggq_gguf_tensor()
         _check(lib.ggq_gguf_find_tensor(self._h, name.encode(), ctypes.byref(t)))
-        return TensorInfo(t)
+        return TensorInfo(t, self._region if self._data_base is not None else None)
 
     def close(self):
         if self._h:
+            self._data_view = None
             lib.ggq_gguf_close(self._h)
             self._h = None
 
@@ -343,6 +360,20 @@ def plan_shards(alignment, meta_kvs, tensors, max_tensor_count=2 ** 64 - 1, max_
 
 # ---- whole-file decode ---------------------------------------------------------------------
 
+_ctx_cache = threading.local()
+
+
+def _thread_context(device, staging_bytes):
+    """One streamed-upload context per (thread, device, staging size), kept for the life of the thread: creating
+    one pins its staging memory, which costs about as long as decoding a 1 B-parameter model."""
+    from .quants import Context
+    cache = _ctx_cache.__dict__.setdefault("ctx", {})
+    key = (int(device), int(staging_bytes))
+    if key not in cache:
+        cache[key] = Context(device, staging_bytes)
+    return cache[key]
+
+
 def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None, group_bytes=1 << 30,
                     stats=None):
     """Decode every tensor of an open GGuf that holds data and has a block type this library
@@ -354,12 +385,12 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
     decoded by ONE launch plan -- one kernel launch per block type present, not one per tensor --
     while the next group's bytes are still on their way.  `stats`, if a dict, receives the counts."""
     import torch
-    from .quants import Batch, Context, SUPPORTED
+    from .quants import Batch, SUPPORTED
     dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out]
     out_ty = {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out]
     supported = {int(x) for x in SUPPORTED}
     dev = f"cuda:{device}"
-    ctx = Context(device, staging_bytes)
+    ctx = _thread_context(device, staging_bytes)
     res, plans = {}, []
     counts = {"tensors": 0, "groups": 0, "launches": 0, "packed_bytes": 0}
 
@@ -373,9 +404,10 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
         for (t, _), o in zip(group, offs):
             ctx.upload_async(arena[o:o + t.nbytes], t.bytes())
-        ctx.sync()                      # this group's bytes have landed; its decode overlaps the next group's upload
+        # the plan needs only addresses: it is built while the last copies are still in flight
         b = Batch([(t.ty, arena[o:o + t.nbytes], dst) for (t, dst), o in zip(group, offs)], out_ty)
-        b.run()
+        ctx.fence()                     # the plan waits on the device for this group's copies; the host goes on
+        b.run()                         # staging the next group meanwhile
         plans.append((b, arena))
         counts["groups"] += 1
         counts["launches"] += b.launches
@@ -408,9 +440,9 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
             ctx.sync()
             torch.cuda.synchronize()
     finally:
+        ctx.sync()                      # also on the error path: nothing of this call may still be in flight
         for b, _ in plans:
             b.close()
-        ctx.close()
     if stats is not None:
         stats.update(counts)
     return res

@@ -333,6 +333,14 @@ class Context:
             raise LengthMismatch()
         check(lib.ggq_upload_async(self._h, dp, sp, sn * ss))
 
+    def fence(self, stream=None):
+        """Later work on `stream` (default: torch's current stream) waits, on the device, for everything
+        enqueued on this context so far."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib.ggq_ctx_fence(self._h, stream))
+
     def sync(self):
         check(lib.ggq_sync(self._h))
 

@@ -198,6 +198,11 @@ ggq_status ggq_dequantize_async(ggq_ctx *ctx, uint32_t ggml_type, uint32_t out_t
  * instead of one launch per tensor.  Source lifetime and ggq_sync as for ggq_dequantize_async.
  * No counterpart in the reference (its tensors stay in the file mapping, xtask/src/utils/read.rs:49-55). */
 ggq_status ggq_upload_async(ggq_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+/* Orders `hip_stream` (on the context's device) behind the context: work enqueued on hip_stream after this
+ * call starts only when everything enqueued on the context so far -- copies and decodes -- has completed.
+ * The host does not wait, so it can go on staging the next tensors while a plan for the ones just uploaded
+ * (ggq_batch_run on hip_stream) waits its turn on the device.  No counterpart in the reference. */
+ggq_status ggq_ctx_fence(ggq_ctx *ctx, void *hip_stream);
 ggq_status ggq_sync(ggq_ctx *ctx);
 void ggq_ctx_destroy(ggq_ctx *ctx);
 
