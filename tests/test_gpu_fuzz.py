@@ -79,3 +79,46 @@ def test_quantize_matches_oracle(oracle, ty, in_ty, blocks, kind, seed):
         assert ok.all(), np.flatnonzero(~ok)[:5]
     else:
         assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+
+
+@settings(**_cfg)
+@given(out=st.sampled_from(["f32", "f16", "bf16"]),
+       plan=st.lists(st.tuples(st.sampled_from(ALL_TYPES), st.one_of(st.integers(0, 40), st.integers(100, 2500)),
+                               st.integers(0, 15), st.booleans()), min_size=1, max_size=12),
+       seed=st.integers(0, 2 ** 31))
+def test_launch_plan_matches_oracle(oracle, out, plan, seed):
+    """A drawn launch plan: up to 12 tensors of drawn types, sizes (also empty ones), source offsets and payload
+    kinds, one output type; every tensor must come out as the oracle decodes it."""
+    import torch as t
+    import gguf_amd as g
+    from gguf_amd import synth
+    from util import same_bits16, first_diff
+    out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    tensors, packed = [], []
+    for i, (ty, blocks, off, adversarial) in enumerate(plan):
+        if ty in (1, 30):
+            blocks *= 41
+            off &= ~7                     # the widening kernel wants its source 8-byte aligned... or takes the scalar path
+            off |= (i & 1) * 2            # so exercise both
+        p = synth.random_blocks(ty, blocks, seed + i, adversarial=adversarial) if blocks else np.zeros(0, dtype=np.uint8)
+        buf = t.empty(p.size + off + 16, dtype=t.uint8, device="cuda")
+        src = buf[off:off + p.size]
+        if p.size:
+            src.copy_(t.from_numpy(p))
+        dst = t.full((blocks * oracle.block_elems(ty),), -1.0, dtype=out_dt, device="cuda")
+        tensors.append((ty, src, dst))
+        packed.append(p)
+    b = g.Batch(tensors, {"f32": g.GGmlType.F32, "f16": g.GGmlType.F16, "bf16": g.GGmlType.BF16}[out])
+    b.run()
+    t.cuda.synchronize()
+    for (ty, _, d), p in zip(tensors, packed):
+        if p.size == 0:
+            continue
+        want = oracle.dequantize(ty, p, o_out)
+        if out == "f32":
+            assert same_bits(d.cpu().numpy(), want), (ty, p.size, first_diff(d.cpu().numpy(), want))
+        else:
+            got = d.view(t.int16).cpu().numpy().view(np.uint16)
+            assert same_bits16(got, want, out), (ty, p.size, first_diff(got, want))
+    b.close()
