@@ -961,4 +961,78 @@ __global__ __launch_bounds__(THR) void deq_one_s(const uint8_t *__restrict__ src
     asm volatile("" ::"v"(touch));
 }
 
+// ---- Q4_K without LDS ------------------------------------------------------------------------------
+// Every lane fetches what it needs straight from global memory (the lines come from L1 / L2 / the
+// memory-side cache after the burst prefetch): the block's 16-byte header with one dwordx4 load (all
+// lanes of a block read the same 16 bytes) and its quants with one dword (f32 out: 4 elements) or
+// dwordx2 (16-bit out: 8 elements) load.  No staging, no barrier; waves are independent.
+// One-shot grid, THR threads, S stores per thread; thread -> elements exactly as in the tile kernel.
+// Requires the source 16-byte aligned (Q4_K blocks are 144 = 9 x 16 bytes).
+template <class O, int THR, int S>
+__global__ __launch_bounds__(THR) void deq_q4k_direct(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                      uint64_t nblocks, Prefetch pf) {
+    constexpr uint32_t ELEMS = THR * O::EPL * S, TB = ELEMS / 256, TBYTES = TB * 144;
+    constexpr uint32_t LINES = (TBYTES + 127) / 128 + 1, TPW = THR / LINES;
+    const uint64_t t = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t rem = nblocks - t * TB;
+    const uint32_t nblk = rem < TB ? (uint32_t)rem : TB;
+    uint32_t touch = 0;
+    if (pf.period) {
+        const uint32_t ph = (uint32_t)(t % pf.period);
+        const uint32_t nb = (pf.period + TPW - 1) / TPW;
+        if (ph < nb) {
+            const uint32_t j = tid / LINES, l = tid % LINES;
+            const uint32_t k = ph * TPW + j;
+            if (j < TPW && k < pf.period) {
+                const uint64_t tt = t - ph + pf.lead + k;
+                if ((tt + 1) * TB <= nblocks) {
+                    const uint8_t *base = src + tt * TBYTES;
+                    const uint8_t *ln = (const uint8_t *)((uintptr_t)base & ~(uintptr_t)127) + 128u * l;
+                    if (ln < base + TBYTES) touch = *(const uint32_t *)ln;
+                }
+            }
+        }
+    }
+    const uint8_t *ts = src + t * TBYTES;
+    typename O::T *out = dst + t * ELEMS;
+    uint4v hdr[S];
+    uint32_t q[S][O::EPL / 4];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const uint32_t el = (i * THR + tid) * O::EPL, bt = el / 256, e = el % 256;
+        if (bt < nblk) {
+            const uint8_t *b = ts + bt * 144;
+            hdr[i] = *(const uint4v *)b;
+            const uint8_t *qp = b + 16 + 32 * (e >> 6) + (e & 31);
+            if constexpr (O::EPL == 4) q[i][0] = *(const uint32_t *)qp;
+            else { const uint2v v = *(const uint2v *)qp; q[i][0] = v.x; q[i][1] = v.y; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        const uint32_t el = (i * THR + tid) * O::EPL, bt = el / 256, e = el % 256;
+        if (bt >= nblk) continue;
+        const float d = h2f(hdr[i].x & 0xFFFFu), dmin = h2f(hdr[i].x >> 16);
+        const uint32_t is = e >> 5, j8 = (is & 3u) * 8u;
+        const uint32_t A = (hdr[i].y >> j8) & 0xFFu, B = (hdr[i].z >> j8) & 0xFFu, C = (hdr[i].w >> j8) & 0xFFu;
+        const bool low = is < 4;
+        const uint32_t sc = low ? (A & 63u) : ((C & 0xFu) | ((A >> 6) << 4));
+        const uint32_t mn = low ? (B & 63u) : ((C >> 4) | ((B >> 6) << 4));
+        const float a = __fmul_rn(d, (float)sc), c = __fmul_rn(dmin, (float)mn);
+        float y[O::EPL];
+#pragma unroll
+        for (uint32_t g = 0; g < O::EPL / 4; ++g) {
+            uint32_t w = (q[i][g] >> (4 * (is & 1))) & 0x0F0F0F0Fu;
+            asm("" : "+v"(w));
+            y[4 * g + 0] = __fsub_rn(__fmul_rn(a, (float)(w & 0xFFu)), c);
+            y[4 * g + 1] = __fsub_rn(__fmul_rn(a, (float)((w >> 8) & 0xFFu)), c);
+            y[4 * g + 2] = __fsub_rn(__fmul_rn(a, (float)((w >> 16) & 0xFFu)), c);
+            y[4 * g + 3] = __fsub_rn(__fmul_rn(a, (float)(w >> 24)), c);
+        }
+        O::template store<true>(out + el, y);
+    }
+    asm volatile("" ::"v"(touch));
+}
+
 }  // namespace ggq

@@ -954,6 +954,34 @@ int main(int argc, char **argv) {
         SDEQ(Q8_0, OutF16, 256, 2, 0, 0, "sdeq Q8_0 f16 thr256 S2 nopf")
         SDEQ(Q8_0, OutF16, 512, 1, 0, 0, "sdeq Q8_0 f16 thr512 S1 nopf")
     }
+    // ---- Q4_K without LDS against the shipped kernel
+    {
+#define DDEQ(O, THR, S, PB, LB, LABEL)                                                                      \
+        {                                                                                                   \
+            constexpr uint32_t ELEMS_ = THR * O::EPL * S, TB_ = ELEMS_ / 256, TBYTES_ = TB_ * 144;          \
+            const uint64_t blocks = elems / 256;                                                            \
+            const unsigned grid = (unsigned)((blocks + TB_ - 1) / TB_);                                     \
+            const double bytes = (double)elems * (0.5625 + sizeof(typename O::T));                          \
+            const uint32_t P = (uint32_t)((PB) / TBYTES_), L = (uint32_t)((LB) / TBYTES_);                  \
+            vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                \
+                              hipLaunchKernelGGL((deq_q4k_direct<O, THR, S>), dim3(grid), dim3(THR), 0, s,  \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{P, L}); }, {}}); \
+        }
+        const uint64_t PB16 = 768ull * 4608, LB16 = 1280ull * 4608, PB32 = 768ull * 2304, LB32 = 1280ull * 2304;
+        DDEQ(OutF16, 256, 1, PB16, LB16, "ddeq Q4K f16 thr256 S1")
+        DDEQ(OutF16, 256, 2, PB16, LB16, "ddeq Q4K f16 thr256 S2")
+        DDEQ(OutF16, 512, 2, PB16, LB16, "ddeq Q4K f16 thr512 S2")
+        DDEQ(OutF16, 256, 4, PB16, LB16, "ddeq Q4K f16 thr256 S4")
+        DDEQ(OutF16, 128, 2, PB16, LB16, "ddeq Q4K f16 thr128 S2")
+        DDEQ(OutF16, 64, 2, PB16, LB16, "ddeq Q4K f16 thr64 S2")
+        DDEQ(OutF32, 256, 1, PB32, LB32, "ddeq Q4K f32 thr256 S1")
+        DDEQ(OutF32, 256, 2, PB32, LB32, "ddeq Q4K f32 thr256 S2")
+        DDEQ(OutF32, 512, 2, PB32, LB32, "ddeq Q4K f32 thr512 S2")
+        DDEQ(OutF32, 256, 4, PB32, LB32, "ddeq Q4K f32 thr256 S4")
+        DDEQ(OutF32, 128, 2, PB32, LB32, "ddeq Q4K f32 thr128 S2")
+        SHIP(Q4K, OutF32, "ddeq ref ship Q4K f32")
+        SHIP(Q4K, OutF16, "ddeq ref ship Q4K f16")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
