@@ -63,6 +63,7 @@ SYMBOLS = {
     "ggq_quantize_device": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
     "ggq_concat_rows_device": (_int, [_u32, ctypes.c_uint64, _vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64), _sz, _vp]),
     "ggq_split_rows_device": (_int, [_u32, ctypes.c_uint64, _vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64), _sz, _vp]),
+    "ggq_scale_device": (_int, [_u32, _vp, _vp, _sz, ctypes.c_double, _vp]),
     "ggq_permute_qk_device": (_int, [_u32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp, _vp]),
     "ggq_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
     "ggq_batch_run": (_int, [_vp, _vp]),

@@ -1,9 +1,12 @@
-"""The reference's `convert` pipeline for the cast operator, with the per-tensor work on the GPU:
+"""The reference's `convert` pipeline, with the per-tensor work on the GPU:
 
     read    Content::new / merge_file        xtask/src/utils/read.rs:4-63
     cast    Operator::cast, Content::cast    xtask/src/utils/operator/cast.rs:11-138, 180-216
     merge   Content::merge_linear            xtask/src/utils/operator/merge.rs:22-268
     permute Content::permute_qk              xtask/src/utils/operator/permute_qk.rs:12-69
+    scale   Content::convert_to_llama        xtask/src/utils/operator/to_llama.rs:26-125
+    filter, sort, set-meta (host only)       xtask/src/utils/operator/mod.rs:58-71, sort.rs, set_meta.rs
+    steps   the `-x` grammar                 xtask/src/convert.rs:38-51
     write   Content::write_files             xtask/src/utils/write.rs:5-100
 
 Input shards are mapped, not read; a tensor that changes type is produced only when the writer of
@@ -12,9 +15,12 @@ re-encoded / rearranged there, and come back through a pinned buffer that the C+
 producer thread per shard keeps the GPU one tensor ahead of the file.  Output file names are the
 caller's business (`stem`); the reference's name grammar is not part of this library.
 """
+import functools
+import math
 import os
 import queue
 import re
+import struct
 import threading
 
 import numpy as np
@@ -173,6 +179,19 @@ class PermuteQK:
         return rearrange.permute_qk(self.ty, self.row_elems, self.rows, self.nh, self.src.device(dev, up))
 
 
+class Scale:
+    """scale_tensor (to_llama.rs:99-125): every element times a factor, in the tensor's type."""
+    lazy = True
+
+    def __init__(self, src, ty, factor):
+        self.src, self.ty, self.factor, self.nbytes = src, ty, factor, src.nbytes
+
+    def device(self, dev, up=None):
+        t = self.src.device(dev, up)
+        # a Borrowed upload may be a view of the producer's arena: never scale that in place
+        return rearrange.scale(self.ty, t, self.factor)
+
+
 def _slice(src, start, nbytes):
     if isinstance(src, Borrowed):                        # stays a view of the mapping
         return Borrowed(None if src.arr is None else src.arr[start:start + nbytes], nbytes)
@@ -269,6 +288,193 @@ _GROUPS = {"attn_q": ("attn", 0), "attn_k": ("attn", 1), "attn_v": ("attn", 2), 
            "ffn_up": ("ffn", 1), "ffn_gate_exps": ("moe", 0), "ffn_up_exps": ("moe", 1)}
 _GROUP_SIZE = {"attn": 3, "ffn": 2, "moe": 2}
 _GROUP_NAME = {"attn": "attn_qkv", "ffn": "ffn_gate_up", "moe": "ffn_gate_up_exps"}
+
+
+# ---- host-only operators: name patterns, tensor order, metadata text ---------------------------------
+
+def compile_patterns(patterns):
+    """compile_patterns (xtask/src/utils/name_pattern.rs:8-58): every run of word characters, dots and
+    stars is one pattern; between dots, an empty piece is one name segment, a piece of stars any number
+    of segments, and a star inside a piece any run of word characters.  A name matches if it matches
+    one pattern as a whole."""
+    def one(pattern):
+        pieces = []
+        for piece in pattern.split("."):
+            if piece == "":
+                pieces.append(r"\w+")
+            elif set(piece) == {"*"}:
+                pieces.append(r"(\w+\.)*\w+")
+            else:
+                pieces.append(re.sub(r"\*+", r"\\w*", piece))
+        return "^" + r"\.".join(pieces) + "$"
+    return re.compile("|".join(one(p) for p in re.findall(r"[\w*.]+", patterns)))
+
+
+# sort.rs:18-49: the order of the middle and last parts of a tensor name
+_MID = ("attn_norm", "attn_norm_2", "ln1", "attn_qkv", "attn_q", "attn_k", "attn_v", "attn.q", "attn.k", "attn.v",
+        "attn_output", "attn_out", "attn.out", "ffn_norm", "ln2", "ffn_gate_inp", "ffn_gate_up", "ffn_gate_up_exps",
+        "ffn_gate_up_exp", "ffn_gate", "ffn_gate_exps", "ffn_gate_exp", "ffn_up", "ffn_up_exps", "ffn_up_exp",
+        "ffn_down", "ffn_down_exps", "ffn_down_exp")
+_POST = ("weight", "bias")
+# alternatives are tried in list order at the leftmost position, as the reference's regex does (so
+# "attn_norm_2" is found as "attn_norm" followed by "_2")
+_MID_RE = re.compile("|".join(m.replace(".", r"\.") for m in _MID))
+_MID_RANK = {m: i for i, m in enumerate(_MID)}
+_POST_RANK = {m: i for i, m in enumerate(_POST)}
+
+
+def _cmp(a, b):
+    return (a > b) - (a < b)
+
+
+def _cmp_by_rank(a, b, rank):
+    """cmp_by_map (sort.rs:170-177): listed names first, in list order; the rest as strings."""
+    ra, rb = rank.get(a), rank.get(b)
+    if ra is not None and rb is None:
+        return -1
+    if ra is None and rb is not None:
+        return 1
+    if ra is not None:
+        return _cmp(ra, rb)
+    return _cmp(a, b)
+
+
+def _name_key(name):
+    """Name::new_key (sort.rs:70-104): (segments before the middle part, middle part, rest)."""
+    m = _MID_RE.search(name)
+    start, end = (m.start(), m.end()) if m else (len(name), len(name))
+    pre = [int(s) if s.isascii() and s.isdigit() else s for s in name[:start].split(".")]
+    return pre, name[start:end], name[end:].split(".")
+
+
+def _cmp_names(x, y):
+    """Ord for Name / Pre / Mid / Post (sort.rs:106-168)."""
+    (pa, ma, sa), (pb, mb, sb) = x, y
+    for a, b in zip(pa, pb):
+        if isinstance(a, str) != isinstance(b, str):
+            return -1 if isinstance(a, str) else 1           # a string segment sorts before a number
+        if a != b:
+            return _cmp(a, b)
+    if len(pa) != len(pb):
+        return _cmp(len(pa), len(pb))
+    c = _cmp_by_rank(ma, mb, _MID_RANK)
+    if c:
+        return c
+    for a, b in zip(sa, sb):
+        c = _cmp_by_rank(a, b, _POST_RANK)
+        if c:
+            return c
+    return _cmp(len(sa), len(sb))
+
+
+_META_TYPES = {"u8": 0, "i8": 1, "u16": 2, "i16": 3, "u32": 4, "i32": 5, "f32": 6, "bool": 7, "str": 8, "arr": 9,
+               "u64": 10, "i64": 11, "f64": 12}
+_INT_RANGE = {0: (0, 2 ** 8), 1: (-2 ** 7, 2 ** 7), 2: (0, 2 ** 16), 3: (-2 ** 15, 2 ** 15), 4: (0, 2 ** 32),
+              5: (-2 ** 31, 2 ** 31), 10: (0, 2 ** 64), 11: (-2 ** 63, 2 ** 63)}
+_INT_FMT = {0: "<B", 1: "<b", 2: "<H", 3: "<h", 4: "<I", 5: "<i", 10: "<Q", 11: "<q"}
+
+
+def _meta_string(text):
+    raw = text.encode()
+    return 8, struct.pack("<Q", len(raw)) + raw
+
+
+def _meta_value(ty, text):
+    """write_val (set_meta.rs:212-249): the value's bytes from its text."""
+    if ty == 8:
+        return _meta_string(text)
+    if ty in _INT_FMT:
+        if not re.fullmatch(r"[+-]?\d+", text):
+            raise ValueError(f"invalid integer: {text!r}")
+        v = int(text)
+        lo, hi = _INT_RANGE[ty]
+        if not lo <= v < hi:
+            raise ValueError(f"integer out of range: {text}")
+        return ty, struct.pack(_INT_FMT[ty], v)
+    if ty in (6, 12):
+        if "_" in text:
+            raise ValueError(f"invalid float: {text!r}")
+        return ty, struct.pack("<f" if ty == 6 else "<d", np.float32(float(text)) if ty == 6 else float(text))
+    if ty == 7:
+        if text not in ("true", "false"):
+            raise ValueError(f"Invalid bool value: {text}")
+        return ty, bytes([text == "true"])
+    raise Unsupported("array values are not supported")          # todo!() in the reference (set_meta.rs:106-108)
+
+
+def parse_meta_cfg(cfg):
+    """Operator::set_meta_by_cfg (set_meta.rs:10-145): lines `'key' type value`; `'key' str "text"` for
+    a one-line string; `'key' str<sep>` followed by lines that start with `<sep> ` for a string of
+    several lines.  Returns {key: (type id, value bytes)} in the order of the text."""
+    out = {}
+    pending = None                       # [key, separator + " ", lines or None, started]
+
+    def save():
+        out[pending[0]] = _meta_string("\n".join(pending[2] or []))
+
+    for line in cfg.split("\n"):
+        line = line[:-1] if line.endswith("\r") else line
+        if pending is not None:
+            if line == "":
+                if pending[3]:           # an empty line ends a string that has begun
+                    save()
+                    pending = None
+                continue
+            if line.startswith(pending[1]):
+                pending[2] = (pending[2] or []) + [line[len(pending[1]):]]
+                pending[3] = True
+                continue
+            save()                       # the string is over; the line is an item of its own
+            pending = None
+        if line == "":
+            continue
+        m = re.match(r"^'((?:\w+\.)*\w+)'\s*(\S+)", line)
+        if not m:
+            raise ValueError(f"Expect meta kv config item: {line!r}")
+        key, ty = m.group(1), m.group(2)
+        val = line[m.end(2):].strip()
+        if ty.startswith("str"):
+            sep = ty[3:]
+            if sep == "":
+                if len(val) < 2 or val[0] != '"' or val[-1] != '"':
+                    raise ValueError(f"{key}: a one-line string stands in double quotes")
+                out[key] = _meta_string(val[1:-1])
+            else:
+                if val:
+                    raise ValueError(f"{key}: a string of several lines starts on the next line")
+                pending = [key, sep + " ", None, False]
+        elif re.match(r"^\[(\w+)\](\S+)?$", ty):
+            raise Unsupported("array values are not supported")
+        else:
+            if ty not in _META_TYPES:
+                raise ValueError(f"Unknown type: {ty}")
+            out[key] = _meta_value(_META_TYPES[ty], val)
+    if pending is not None:
+        save()
+    return out
+
+
+def parse_steps(steps):
+    """The `-x` argument of `convert` (xtask/src/convert.rs:38-51): steps separated by "->"."""
+    out = []
+    for op in steps.split("->"):
+        op = op.strip()
+        if op == "sort":
+            out.append(("sort",))
+        elif op == "permute-qk":
+            out.append(("permute-qk",))
+        elif op == "merge-linear":
+            out.append(("merge-linear", True))
+        elif op in ("split-linear", "!merge-linear"):
+            out.append(("merge-linear", False))
+        elif op == "to-llama":
+            out.append(("to-llama", ""))
+        else:
+            head, sep, rest = op.partition(":")
+            if not sep or head not in ("cast", "to-llama", "filter-meta", "filter-tensor"):
+                raise Unsupported(f"Unsupported operation: {op}")
+            out.append((head, rest))
+    return out
 
 
 class Content:
@@ -400,6 +606,114 @@ class Content:
             else:
                 q, k, v = split_qkv(t, nh, nkvh)
                 self.tensors[name] = merge_qkv(permute_qk_tensor(q, nh), permute_qk_tensor(k, nkvh), v)
+
+    # ---- host-only operators (operator/mod.rs:58-71) --------------------------------------------
+
+    def filter_meta_key(self, patterns):
+        r = compile_patterns(patterns)
+        self.meta_kvs = {k: v for k, v in self.meta_kvs.items() if r.search(k)}
+
+    def filter_tensor_name(self, patterns):
+        r = compile_patterns(patterns)
+        self.tensors = {k: v for k, v in self.tensors.items() if r.search(k)}
+
+    def sort_tensors(self):
+        """Content::sort_tensors (sort.rs:7-15)."""
+        order = sorted(self.tensors, key=functools.cmp_to_key(lambda a, b: _cmp_names(_name_key(a), _name_key(b))))
+        self.tensors = {k: self.tensors[k] for k in order}
+
+    def set_meta(self, items):
+        """Content::set_meta (set_meta.rs:26-55).  `items`: the configuration text, or {key: (type id,
+        value bytes)}.  Keys that exist keep their place; new ones are appended; `general.alignment`
+        sets the alignment of the output; `split.*` keys are refused."""
+        if isinstance(items, str):
+            items = parse_meta_cfg(items)
+        items = dict(items)
+        for k in self.meta_kvs:
+            if k in items:
+                self.meta_kvs[k] = items.pop(k)
+        for k, (ty, raw) in items.items():
+            if k == "general.alignment":
+                if ty != 4 or len(raw) != 4:
+                    raise GGufError(7, k)
+                self.alignment = int.from_bytes(raw, "little")
+            elif k.startswith("split."):
+                raise ValueError(f"Split is not allowed: {k}")
+            else:
+                self.meta_kvs[k] = (ty, raw)
+
+    def to_llama(self, extra=""):
+        """Content::convert_to_llama (to_llama.rs:26-97).  A llama model stays as it is.  MiniCPM:
+        token_embd times the embedding scale, every attn_output and ffn_down times residual scale /
+        sqrt(block count), the three scale keys dropped, `minicpm.*` keys renamed to `llama.*`.
+        `extra`: "embd_scale=<num> res_scale=<num>" overrides the file's values."""
+        arch = self.general_architecture()
+        if arch == "llama":
+            return
+        if arch != "minicpm":
+            raise Unsupported(f"Unsupported architecture: {arch}")
+        if isinstance(extra, str):
+            extra = dict(re.findall(r"(\w+)=(\w+)", extra))
+        keys = {n: f"minicpm.{n}" for n in ("embedding_scale", "residual_scale", "logit_scale")}
+
+        def f32_key(key):
+            if key not in self.meta_kvs:
+                return None
+            ty, raw = self.meta_kvs[key]
+            if ty != 6:
+                raise GGufError(11, key)
+            return float(struct.unpack("<f", raw)[0])
+
+        ty, raw = self.meta_kvs.get("minicpm.block_count", (None, None))
+        if ty not in _INT_FMT:
+            raise KeyError("Missing llm_block_count")
+        nblk = struct.unpack(_INT_FMT[ty], raw)[0]
+        embd, res = f32_key(keys["embedding_scale"]), f32_key(keys["residual_scale"])
+        if "embd_scale" in extra:
+            embd = float(extra["embd_scale"])
+        if "res_scale" in extra:
+            res = float(extra["res_scale"])
+        if embd is None or res is None:
+            raise ValueError('convert from minicpm requires extra args "embd_scale=<num> res_scale=<num>"')
+        res = res / math.sqrt(float(nblk))
+        blk = re.compile(r"^blk\.(\d+)\.(\w+)\.weight$")
+        for name, t in self.tensors.items():
+            m = blk.match(name)
+            factor = embd if name == "token_embd.weight" else \
+                res if m and m.group(2) in ("attn_output", "ffn_down") else None
+            if factor is not None:
+                if t.ty not in (GGmlType.F32, GGmlType.F16, GGmlType.BF16, GGmlType.F64):
+                    raise Unsupported(f"unsupported tensor type: {t.ty!r}")
+                t.data = Scale(t.data, t.ty, factor)
+        # set_arch (to_llama.rs:84-97)
+        old, self.meta_kvs = self.meta_kvs, {}
+        for k, v in old.items():
+            if k == "general.architecture":
+                self.meta_kvs[k] = _meta_string("llama")
+            elif k not in keys.values():
+                self.meta_kvs["llama." + k[len("minicpm."):] if k.startswith("minicpm.") else k] = v
+
+    def apply(self, step):
+        """Content::apply (operator/mod.rs:59-71) for one parsed step of `parse_steps`."""
+        op = step[0]
+        if op == "cast":
+            self.cast(step[1])
+        elif op == "merge-linear":
+            self.merge_linear(step[1])
+        elif op == "permute-qk":
+            self.permute_qk()
+        elif op == "sort":
+            self.sort_tensors()
+        elif op == "to-llama":
+            self.to_llama(step[1] if len(step) > 1 else "")
+        elif op == "filter-meta":
+            self.filter_meta_key(step[1])
+        elif op == "filter-tensor":
+            self.filter_tensor_name(step[1])
+        elif op == "set-meta":
+            self.set_meta(step[1])
+        else:
+            raise Unsupported(f"unknown step {op}")
 
     # ---- writing ------------------------------------------------------------------------------
 
@@ -598,18 +912,14 @@ class _Producer:
 
 
 def convert(inputs, out_dir, stem, steps=(), cast=None, **write_args):
-    """`convert <inputs> -x <steps>`: read, apply the steps in order, write.  A step is
-    ("cast", "linear:f32 ..."), ("merge-linear", True|False) or ("permute-qk",), the operator names
-    of the reference's command line.  Returns the FileInfo list."""
-    steps = list(steps) + ([("cast", cast)] if cast else [])
+    """`convert <inputs> -x <steps>`: read, apply the steps in order, write.  `steps` is the reference's
+    step string ("sort->cast:linear:f16->permute-qk", convert.rs:13) or a list of parsed steps:
+    ("cast", "linear:f32 ..."), ("merge-linear", True|False), ("permute-qk",), ("sort",), ("to-llama", extra),
+    ("filter-meta", patterns), ("filter-tensor", patterns), ("set-meta", text or dict).
+    Returns the FileInfo list."""
+    steps = parse_steps(steps) if isinstance(steps, str) else list(steps)
+    steps += [("cast", cast)] if cast else []
     with Content(inputs) as c:
         for step in steps:
-            if step[0] == "cast":
-                c.cast(step[1])
-            elif step[0] == "merge-linear":
-                c.merge_linear(step[1])
-            elif step[0] == "permute-qk":
-                c.permute_qk()
-            else:
-                raise Unsupported(f"unknown step {step[0]}")
+            c.apply(step)
         return c.write_files(out_dir, stem, **write_args)

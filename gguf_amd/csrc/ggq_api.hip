@@ -8,6 +8,7 @@
 #include "quantize.h"
 #include "schedule.h"
 #include "rearrange.h"
+#include "scale.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -303,6 +304,79 @@ ggq_status launch_quant_in(uint32_t ty, uint32_t in_ty, void *d_dst, const void 
     case GGQ_TYPE_BF16: return launch_quant<InBF16>(ty, d_dst, d_src, blocks, cus, st);
     default: return GGQ_UNSUPPORTED;
     }
+}
+
+// ---- scaling ----------------------------------------------------------------------
+// The factor in the tensor's type, as the reference converts it (to_llama.rs:102-105).  f32 is `scale as f32`.
+// f16 is f16::from_f64 of the crate `half`, which on an x86 host with F16C narrows through f32 (two
+// round-to-nearest-even steps); bf16 is bf16::from_f64, the crate's software routine, which drops the low 32 bits
+// of the f64 before it rounds to nearest even.
+static uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x > 0x7F800000u) return (uint16_t)(sign | 0x7E00u | ((x >> 13) & 0x3FFu));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);     // 65520 and above round to infinity
+    if (x < 0x38800000u) {
+        // below 2^-14: next to 0.5 one unit in the last place is 2^-24, so the addition rounds to half's subnormal grid
+        float v;
+        memcpy(&v, &x, 4);
+        v += 0.5f;
+        uint32_t y;
+        memcpy(&y, &v, 4);
+        return (uint16_t)(sign | (y - 0x3F000000u));
+    }
+    x += 0xC8000FFFu + ((x >> 13) & 1u);                         // rebias the exponent by -112, round half to even
+    return (uint16_t)(sign | (x >> 13));
+}
+
+static uint16_t f64_to_bf16_bits(double v) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const uint32_t hi = (uint32_t)(bits >> 32);
+    const uint32_t sign = (hi >> 16) & 0x8000u, e11 = (hi >> 20) & 0x7FFu;
+    uint32_t frac = hi & 0xFFFFFu;
+    if (e11 == 0x7FFu) {
+        const bool nan = frac != 0 || (uint32_t)bits != 0;
+        return (uint16_t)(sign | 0x7F80u | (nan ? 0x40u : 0u) | (frac >> 13));
+    }
+    const int e8 = (int)e11 - 1023 + 127;
+    if (e8 >= 0xFF) return (uint16_t)(sign | 0x7F80u);
+    uint32_t drop = 13, base = 0;
+    if (e8 <= 0) {
+        if (7 - e8 > 21) return (uint16_t)sign;
+        frac |= 0x100000u;
+        drop = (uint32_t)(14 - e8);
+    } else {
+        base = (uint32_t)e8 << 7;
+    }
+    uint32_t q = base | (frac >> drop);
+    const uint32_t round_bit = 1u << (drop - 1);
+    if ((frac & round_bit) && (frac & (3u * round_bit - 1u))) ++q;
+    return (uint16_t)(sign | q);
+}
+
+template <uint32_t K>
+static ggq_status launch_scale(void *d_dst, const void *d_src, uint64_t elems, uint64_t factor, hipStream_t q) {
+    constexpr uint64_t EB = ScaleOp<K>::BYTES, PER = 16 / EB;
+    uint64_t vec_elems = 0;
+    if (((uintptr_t)d_dst | (uintptr_t)d_src) % 16 == 0) {
+        const uint64_t pieces = elems / PER;
+        vec_elems = pieces * PER;
+        const uint64_t wgs = (pieces + STREAM_THREADS - 1) / STREAM_THREADS;
+        for (uint64_t w0 = 0; w0 < wgs; w0 += kMaxGrid)
+            hipLaunchKernelGGL((scale_vec<K>), dim3((uint32_t)std::min(kMaxGrid, wgs - w0)), dim3(STREAM_THREADS), 0, q,
+                               (uint4v *)d_dst, (const uint4v *)d_src, pieces, w0 * STREAM_THREADS, factor);
+    }
+    const uint64_t rest = elems - vec_elems;
+    const uint64_t wgs = (rest + STREAM_THREADS - 1) / STREAM_THREADS;
+    for (uint64_t w0 = 0; w0 < wgs; w0 += kMaxGrid)
+        hipLaunchKernelGGL((scale_scalar<K>), dim3((uint32_t)std::min(kMaxGrid, wgs - w0)), dim3(STREAM_THREADS), 0, q,
+                           (uint8_t *)d_dst + vec_elems * EB, (const uint8_t *)d_src + vec_elems * EB, rest,
+                           w0 * STREAM_THREADS, factor);
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
 }
 
 // ---- batch ------------------------------------------------------------------------
@@ -862,6 +936,28 @@ ggq_status ggq_permute_qk_device(uint32_t ty, uint64_t row_elems, uint64_t rows,
     }
     HIP_TRY(hipGetLastError());
     return GGQ_OK;
+}
+
+// ---- scaling ----------------------------------------------------------------------
+ggq_status ggq_scale_device(uint32_t ty, void *d_dst, const void *d_src, size_t elems, double scale, void *hip_stream) {
+    if (ty != 0 && ty != 1 && ty != 30 && ty != 28) return GGQ_UNSUPPORTED;       // F32, F16, BF16, F64
+    if (elems == 0) return GGQ_OK;
+    if (!d_dst || !d_src) return GGQ_INVALID;
+    const uint64_t eb = ty == 28 ? 8 : ty == 0 ? 4 : 2;
+    if (((uintptr_t)d_dst | (uintptr_t)d_src) % eb != 0) return GGQ_MISALIGNED;
+    hipStream_t q = (hipStream_t)hip_stream;
+    uint64_t factor = 0;
+    if (ty == 0) {
+        const float f = (float)scale;
+        uint32_t b;
+        memcpy(&b, &f, 4);
+        factor = b;
+        return launch_scale<SC_F32>(d_dst, d_src, elems, factor, q);
+    }
+    if (ty == 1) return launch_scale<SC_F16>(d_dst, d_src, elems, f32_to_f16_bits((float)scale), q);
+    if (ty == 30) return launch_scale<SC_BF16>(d_dst, d_src, elems, f64_to_bf16_bits(scale), q);
+    memcpy(&factor, &scale, 8);
+    return launch_scale<SC_F64>(d_dst, d_src, elems, factor, q);
 }
 
 // ---- batch ------------------------------------------------------------------------

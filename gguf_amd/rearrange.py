@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's block-granular tensor operators, on device tensors:
 merge_qkv / merge_gate_up (concat along rows), split_qkv / split_gate_up, permute_qk
-(xtask/src/utils/operator/merge.rs:224-268, permute_qk.rs:46-69).  Tensors are uint8 CUDA
+(xtask/src/utils/operator/merge.rs:224-268, permute_qk.rs:46-69), and to-llama's scale_tensor
+(to_llama.rs:99-125).  Tensors are uint8 CUDA
 tensors holding packed rows; shapes are (row_elems, rows) with row_elems contiguous, as in GGUF.
 """
 import ctypes
@@ -62,4 +63,24 @@ def permute_qk(ty, row_elems, rows, n_head, src):
     import torch
     out = torch.empty_like(src)
     check(lib.ggq_permute_qk_device(int(ty), row_elems, rows, n_head, out.data_ptr(), src.data_ptr(), _stream()))
+    return out
+
+
+_SCALABLE = {0: 4, 1: 2, 30: 2, 28: 8}       # F32, F16, BF16, F64: bytes per element
+
+
+def scale(ty, src, factor, out=None):
+    """scale_tensor (to_llama.rs:99-125): every element of a float tensor (uint8 device tensor of F32,
+    F16, BF16 or F64 data) times `factor`, computed in the tensor's type.  `out` may be `src`."""
+    import torch
+    eb = _SCALABLE.get(int(ty))
+    if eb is None:
+        from .quants import Unsupported
+        raise Unsupported(f"unsupported tensor type: {ty!r}")
+    if src.numel() % eb:
+        from .quants import Indivisible
+        raise Indivisible()
+    if out is None:
+        out = torch.empty_like(src)
+    check(lib.ggq_scale_device(int(ty), out.data_ptr(), src.data_ptr(), src.numel() // eb, float(factor), _stream()))
     return out

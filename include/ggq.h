@@ -143,6 +143,18 @@ ggq_status ggq_split_rows_device(uint32_t ggml_type, uint64_t row_elems, const v
 ggq_status ggq_permute_qk_device(uint32_t ggml_type, uint64_t row_elems, uint64_t rows, uint64_t n_head,
                                  void *d_dst, const void *d_src, void *hip_stream);
 
+/* ---- scaling a float tensor ---------------------------------------------------
+ * Device form of `scale_tensor` / `scale_data` of the reference's to-llama operator
+ * (xtask/src/utils/operator/to_llama.rs:99-125): d_dst[i] = d_src[i] * scale over `elems`
+ * elements of type F32 (0), F16 (1), BF16 (30) or F64 (28), computed in that type: the factor
+ * is converted to the type first, as the reference does (`scale as f32`, f16::from_f64,
+ * bf16::from_f64), and every product is rounded once, to nearest even.  Other types:
+ * GGQ_UNSUPPORTED (`todo!()` in the reference).  d_dst may equal d_src; both must be aligned
+ * to the element size (GGQ_MISALIGNED), 16-byte alignment of both takes the fast path.
+ * Enqueues on `hip_stream`, does not synchronize. */
+ggq_status ggq_scale_device(uint32_t ggml_type, void *d_dst, const void *d_src, size_t elems,
+                            double scale, void *hip_stream);
+
 /* ---- dequantize, batch of device-resident tensors -------------------------
  * One call decodes many tensors (a whole model's tensor table) with one kernel
  * launch per block type present, instead of one per tensor.  Stands in for the

@@ -20,6 +20,7 @@
  *   Q8_1 ........................... ggml-quants/src/structs/q8_1.rs:28-61
  *   Q8K (reference layout, 290 B) .. ggml-quants/src/structs/q8_k.rs:27-60
  *   block sizing ................... ggus/src/tensor.rs:83-96, 102-144
+ *   to-llama's tensor scaling ...... xtask/src/utils/operator/to_llama.rs:99-125
  *
  * Pinning status.
  *   The reference is Rust and cannot be built in this environment, and it
@@ -40,6 +41,14 @@
  * (Cargo.lock pins 2.6.0), which is not vendored.  Its published behaviour:
  * widening is exact and quiets signalling NaNs; narrowing is IEEE
  * round-to-nearest-even, NaN -> sign | exp all ones | quiet bit | top payload.
+ * From f64 (used only for the scaling factor): f16::from_f64 picks its routine
+ * at run time -- on an x86 host with F16C it narrows `f as f32` with the
+ * hardware instruction, i.e. two round-to-nearest-even steps, which is what is
+ * restated here; its portable routine and bf16::from_f64 work on the upper 32
+ * bits of the f64 only (the lower 32 are dropped before rounding).  These
+ * routines are restated from the crate's published source as remembered, with
+ * no copy of it at hand: for factors within one rounding step of a tie the
+ * factor conversion is PARITY UNPINNED.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see Makefile).
  * -ffp-contract=off matters: Rust never fuses a*b+c.
@@ -752,6 +761,72 @@ int ggo_quantize_slice(uint32_t ty, uint32_t in_ty, void *dst, size_t dst_blocks
     for (size_t b = 0; b < dst_blocks; ++b) {
         for (size_t k = 0; k < n; ++k) tmp[k] = load_in(src, in_ty, b * n + k);
         fn(tmp, out + b * bb);
+    }
+    return GGO_OK;
+}
+
+/* ======================================================================== *
+ *  to-llama: scale a float tensor (to_llama.rs:99-125)                     *
+ * ======================================================================== */
+
+/* f16::from_f64 on an x86 host with F16C: through f32 (see the header). */
+uint16_t ggo_f64_to_f16(double v) { return ggo_f32_to_f16((float)v); }
+
+/* bf16::from_f64 of half 2.6.0: the crate's software routine. */
+uint16_t ggo_f64_to_bf16(double value)
+{
+    uint64_t val;
+    memcpy(&val, &value, 8);
+    uint32_t x = (uint32_t)(val >> 32);      /* the last 32 bits of mantissa are truncated */
+    uint32_t sign = x & 0x80000000u;
+    uint32_t exp = x & 0x7FF00000u;
+    uint32_t man = x & 0x000FFFFFu;
+    if (exp == 0x7FF00000u) {
+        uint32_t nan_bit = (man == 0 && (uint32_t)val == 0) ? 0 : 0x0040u;
+        return (uint16_t)((sign >> 16) | 0x7F80u | nan_bit | (man >> 13));
+    }
+    uint32_t half_sign = sign >> 16;
+    int64_t unbiased_exp = (int64_t)(exp >> 20) - 1023;
+    int64_t half_exp = unbiased_exp + 127;
+    if (half_exp >= 0xFF) return (uint16_t)(half_sign | 0x7F80u);
+    if (half_exp <= 0) {
+        if (7 - half_exp > 21) return (uint16_t)half_sign;
+        man |= 0x00100000u;
+        uint32_t half_man = man >> (14 - half_exp);
+        uint32_t round_bit = 1u << (13 - half_exp);
+        if ((man & round_bit) != 0 && (man & (3 * round_bit - 1)) != 0) half_man += 1;
+        return (uint16_t)(half_sign | half_man);
+    }
+    uint32_t he = (uint32_t)half_exp << 7;
+    uint32_t half_man = man >> 13;
+    uint32_t round_bit = 0x00001000u;
+    if ((man & round_bit) != 0 && (man & (3 * round_bit - 1)) != 0)
+        return (uint16_t)((half_sign | he | half_man) + 1);
+    return (uint16_t)(half_sign | he | half_man);
+}
+
+/* scale_tensor + scale_data: `*x *= scale` in the tensor's type.  For f16 / bf16 the crate's
+ * Mul is from_f32(a.to_f32() * b.to_f32()). */
+int ggo_scale(uint32_t ty, void *dst, const void *src, size_t n, double scale)
+{
+    enum { T_F64 = 28 };
+    if (ty == T_F64) {
+        const double *s = (const double *)src; double *d = (double *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = s[i] * scale;
+    } else if (ty == T_F32) {
+        const float f = (float)scale;
+        const float *s = (const float *)src; float *d = (float *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = s[i] * f;
+    } else if (ty == T_F16) {
+        const float f = ggo_f16_to_f32(ggo_f64_to_f16(scale));
+        const uint16_t *s = (const uint16_t *)src; uint16_t *d = (uint16_t *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = ggo_f32_to_f16(ggo_f16_to_f32(s[i]) * f);
+    } else if (ty == T_BF16) {
+        const float f = ggo_bf16_to_f32(ggo_f64_to_bf16(scale));
+        const uint16_t *s = (const uint16_t *)src; uint16_t *d = (uint16_t *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = ggo_f32_to_bf16(ggo_bf16_to_f32(s[i]) * f);
+    } else {
+        return GGO_UNSUPPORTED;      /* todo!() in the reference */
     }
     return GGO_OK;
 }

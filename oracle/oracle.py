@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libggq_oracle.so")
 OK, INDIVISIBLE, LENGTH_MISMATCH, UNSUPPORTED = 0, 1, 2, 3
 
 # GGmlType discriminants (ggus/src/tensor.rs:14-51)
-F32, F16, BF16 = 0, 1, 30
+F32, F16, BF16, F64 = 0, 1, 30, 28
 Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 2, 3, 6, 7, 8, 9
 Q2K, Q3K, Q4K, Q5K, Q6K, Q8K = 10, 11, 12, 13, 14, 15
 IQ4NL, IQ4XS = 20, 23
@@ -59,6 +59,12 @@ def lib():
         L.ggo_quantize_slice.argtypes = [
             ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
             ctypes.c_void_p, ctypes.c_size_t]
+        L.ggo_scale.restype = ctypes.c_int
+        L.ggo_scale.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double]
+        L.ggo_f64_to_f16.restype = ctypes.c_uint16
+        L.ggo_f64_to_f16.argtypes = [ctypes.c_double]
+        L.ggo_f64_to_bf16.restype = ctypes.c_uint16
+        L.ggo_f64_to_bf16.argtypes = [ctypes.c_double]
         _lib = L
     return _lib
 
@@ -116,3 +122,13 @@ def f32_to_f16(vals):
     L = lib()
     return np.array([L.ggo_f32_to_f16(float(v)) for v in
                      np.asarray(vals, dtype=np.float32).reshape(-1)], dtype=np.uint16)
+
+
+def scale(ty, values, factor):
+    """Every element times `factor` in the tensor's type (float32 / float64 arrays, or uint16 bit
+    patterns for f16 / bf16)."""
+    values = np.ascontiguousarray(values).reshape(-1)
+    out = np.empty_like(values)
+    st = lib().ggo_scale(ty, out.ctypes.data, values.ctypes.data, values.size, float(factor))
+    assert st == OK, st
+    return out

@@ -1,4 +1,4 @@
-"""The kernels beside the f32 decode -- quantize, widen, narrow, the permute_qk row gather -- run a few
+"""The kernels beside the f32 decode -- quantize, widen, narrow, the permute_qk row gather, scale -- run a few
 times each on 1 Gi elements, for `rocprofv3 --kernel-trace --stats` (profiles/summarize_misc.py prices
 the averages against 8 TB/s).  Run on the GPU box."""
 import json
@@ -46,5 +46,15 @@ src = torch.randint(0, 255, (rows * 2304,), dtype=torch.uint8, device="cuda")
 for _ in range(reps):
     out = R.permute_qk(T.Q4K, 4096, rows, rows // 128, src)
 bytes_per_launch["permute_qk_rows<16"] = 2 * rows * 2304
+torch.cuda.synchronize()
+del src, out
+
+# scale: 1 Gi elements of f16 and of f32, out of place
+for ty, buf, key in ((T.F16, h.view(torch.uint8), "scale_vec<1"), (T.F32, x.view(torch.uint8), "scale_vec<0")):
+    dst = torch.empty_like(buf)
+    for _ in range(reps):
+        R.scale(ty, buf, 1.4, out=dst)
+    bytes_per_launch[key] = 2 * buf.numel()
+    del dst
 torch.cuda.synchronize()
 print(json.dumps(bytes_per_launch))
