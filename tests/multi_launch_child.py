@@ -82,4 +82,20 @@ src = np.random.default_rng(6).integers(0, 256, 64 * rb, dtype=np.uint8)
 got = R.permute_qk(12, 4096, 64, 4, t.from_numpy(src).cuda())
 t.cuda.synchronize()
 assert np.array_equal(got.cpu().numpy(), np_permute_qk(src, rb, 64, 4)), "permute"
+
+# scale: 10 workgroups of 16-byte pieces plus a tail of single elements, aligned and from an odd address
+for ty, npdt in ((0, np.float32), (1, np.uint16), (30, np.uint16), (28, np.float64)):
+    eb = np.dtype(npdt).itemsize
+    nel = 10 * 256 * (16 // eb) + 3 * 256 + 5
+    v = np.random.default_rng(7 + ty).standard_normal(nel)
+    host = v.astype(npdt) if ty in (0, 28) else v.astype(np.float16).view(np.uint16) if ty == 1 else \
+        (v.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    want = o.scale(ty, host, 1.4).view(np.uint8)
+    dev = t.empty(host.nbytes + 16, dtype=t.uint8, device="cuda")
+    for off in (0, eb):
+        view = dev[off:off + host.nbytes]
+        view.copy_(t.from_numpy(host.view(np.uint8).copy()))
+        got = R.scale(ty, view, 1.4)
+        t.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want), ("scale", ty, off)
 print("OK")
