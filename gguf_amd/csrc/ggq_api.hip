@@ -388,7 +388,7 @@ ggq_status launch_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hi
         for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                     \
             uint64_t n = std::min(kMaxGrid, ntiles - t0);                                        \
             hipLaunchKernelGGL((deq_batch<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
-                               d_table + t0, n, pick_prefetch(ID, out_id<O>(), true));          \
+                               d_table, t0, ntiles, pick_prefetch(ID, out_id<O>(), true));      \
         }                                                                                        \
         break;
         GGQ_FORMATS(X)
@@ -408,7 +408,7 @@ struct ggq_batch {
     uint32_t out_ty = 0;
     struct Group {
         uint32_t ty;
-        uint64_t first, ntiles;   // range in the device tile table
+        uint64_t first, ntiles;   // first record in the device tile table (a multiple of 64), tiles in the group
     };
     std::vector<Group> groups;
     // F16 / BF16 tensors are widened one launch each
@@ -1012,7 +1012,7 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
             g.ntiles += (tensors[i].blocks + hg.blocks - 1) / hg.blocks;
             ++sp.ndesc;
         }
-        total_tiles += g.ntiles;
+        total_tiles += (g.ntiles + 63) / 64 * 64;      // record_slot() permutes within runs of 64
         b->groups.push_back(g);
         spans.push_back(sp);
     }
@@ -1027,10 +1027,15 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
             const HostGeom hg = host_geom(type_info(g.ty), out_ty);
             for (uint64_t t0 = 0; t0 < g.ntiles; t0 += kMaxGrid * 256) {
                 const uint64_t end = std::min(g.ntiles, t0 + kMaxGrid * 256);
-                hipLaunchKernelGGL(build_tile_table, dim3((uint32_t)((end - t0 + 255) / 256)), dim3(256), 0,
-                                   (hipStream_t)0, b->d_table + g.first, d_desc + spans[k].desc0,
-                                   (uint32_t)spans[k].ndesc, t0, end, (uint32_t)hg.blocks, (uint32_t)hg.bytes,
-                                   (uint32_t)(hg.elems * ob));
+                const dim3 grid((uint32_t)((end - t0 + 255) / 256)), wg(256);
+                if (out_ty == GGQ_TYPE_F32)
+                    hipLaunchKernelGGL(build_tile_table<RecordOrder<OutF32>::PER_XCD>, grid, wg, 0, (hipStream_t)0,
+                                       b->d_table + g.first, d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end,
+                                       (uint32_t)hg.blocks, (uint32_t)hg.bytes, (uint32_t)(hg.elems * ob));
+                else
+                    hipLaunchKernelGGL(build_tile_table<RecordOrder<OutF16>::PER_XCD>, grid, wg, 0, (hipStream_t)0,
+                                       b->d_table + g.first, d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end,
+                                       (uint32_t)hg.blocks, (uint32_t)hg.bytes, (uint32_t)(hg.elems * ob));
             }
             ok = hip_ok(hipGetLastError(), "build_tile_table");
         }

@@ -1035,4 +1035,32 @@ __global__ __launch_bounds__(THR) void deq_q4k_direct(const uint8_t *__restrict_
     asm volatile("" ::"v"(touch));
 }
 
+// ---- batch kernel with an XCD-aware record layout -------------------------------------------------------
+// Workgroups go to the 8 XCDs in round robin, so the records of tiles t, t+1, ..., t+7 are each read by a
+// different L2 and every workgroup misses on its record's line.  Here the record of tile t sits at slot
+// (t & ~63) | ((t & 7) << 3) | ((t >> 3) & 7): the 8 records one XCD reads out of every 64 tiles share a
+// 128-byte line.  PERM = false is the shipped layout (control).
+__device__ __forceinline__ uint64_t xcd_slot(uint64_t t) { return (t & ~63ull) | ((t & 7ull) << 3) | ((t >> 3) & 7ull); }
+
+template <class F, class O, bool PERM, int AHEAD = 0>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_px(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const TileRef me = table[PERM ? xcd_slot(t) : t];
+    // AHEAD > 0: the first of the 8 workgroups that share a record line also touches the line that this XCD's
+    // workgroups will read AHEAD runs of 64 tiles later
+    uint32_t touch2 = 0;
+    if (AHEAD > 0 && ((t >> 3) & 7) == 0 && threadIdx.x == 0 && t + 64ull * AHEAD < ntiles)
+        touch2 = *(const uint32_t *)&table[xcd_slot(t + 64ull * AHEAD)];
+    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[PERM ? xcd_slot(tt) : tt].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)me.dst, line);
+    asm volatile("" ::"v"(touch2));
+}
+
 }  // namespace ggq

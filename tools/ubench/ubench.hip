@@ -133,15 +133,16 @@ void add_sweep_batch(std::vector<UbVariant> &vs, const char *name, const uint8_t
     typedef TileGeom<F, O> G;
     const uint64_t blocks = elems / F::N;
     const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;
-    std::vector<TileRef> tab(ntiles);
+    const uint64_t slots = (ntiles + 63) / 64 * 64;
+    std::vector<TileRef> tab(slots);
     for (uint64_t t = 0; t < ntiles; ++t) {
         uint64_t nblk = std::min<uint64_t>(G::TB, blocks - t * G::TB);
-        tab[t] = {((uint64_t)(uintptr_t)d_in + t * G::TBYTES) | (nblk << 48),
-                  (uint64_t)(uintptr_t)d_out + t * G::ELEMS * sizeof(typename O::T)};
+        tab[record_slot<RecordOrder<O>::PER_XCD>(t)] = {((uint64_t)(uintptr_t)d_in + t * G::TBYTES) | (nblk << 48),
+                                                        (uint64_t)(uintptr_t)d_out + t * G::ELEMS * sizeof(typename O::T)};
     }
     TileRef *d_tab;
-    CK(hipMalloc(&d_tab, ntiles * sizeof(TileRef)));
-    CK(hipMemcpy(d_tab, tab.data(), ntiles * sizeof(TileRef), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_tab, slots * sizeof(TileRef)));
+    CK(hipMemcpy(d_tab, tab.data(), slots * sizeof(TileRef), hipMemcpyHostToDevice));
     const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
     static const uint32_t periods[] = {0, 1, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 3072, 4096};
     static const uint32_t leads[] = {512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 6144};
@@ -153,8 +154,47 @@ void add_sweep_batch(std::vector<UbVariant> &vs, const char *name, const uint8_t
             std::snprintf(label, sizeof label, "%s %s P%u L%u", g_sweep_tag[2] ? g_sweep_tag : "swb", name, P, P ? L : 0);
             vs.push_back({label, bytes, [=](hipStream_t s) {
                               hipLaunchKernelGGL((deq_batch<F, O, true>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s,
-                                                 d_tab, ntiles, Prefetch{P, L}); }, {}});
+                                                 d_tab, (uint64_t)0, ntiles, Prefetch{P, L}); }, {}});
         }
+}
+
+// batch kernel with the records laid out per XCD (deq_batch_px) against the shipped layout, at the shipped schedule
+template <class F, class O>
+void add_batch_px(std::vector<UbVariant> &vs, const char *name, const uint8_t *d_in, void *d_out, uint64_t elems, Prefetch pf, Prefetch ps) {
+    typedef TileGeom<F, O> G;
+    const uint64_t blocks = elems / F::N;
+    const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;
+    const uint64_t slots = (ntiles + 63) / 64 * 64;
+    std::vector<TileRef> tab(slots), perm(slots);
+    for (uint64_t t = 0; t < ntiles; ++t) {
+        uint64_t nblk = std::min<uint64_t>(G::TB, blocks - t * G::TB);
+        tab[t] = {((uint64_t)(uintptr_t)d_in + t * G::TBYTES) | (nblk << 48),
+                  (uint64_t)(uintptr_t)d_out + t * G::ELEMS * sizeof(typename O::T)};
+        perm[(t & ~63ull) | ((t & 7ull) << 3) | ((t >> 3) & 7ull)] = tab[t];
+    }
+    TileRef *d_tab, *d_perm;
+    CK(hipMalloc(&d_tab, slots * sizeof(TileRef)));
+    CK(hipMalloc(&d_perm, slots * sizeof(TileRef)));
+    CK(hipMemcpy(d_tab, tab.data(), slots * sizeof(TileRef), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_perm, perm.data(), slots * sizeof(TileRef), hipMemcpyHostToDevice));
+    const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
+    char label[96];
+    std::snprintf(label, sizeof label, "bpx %s records in tile order", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_batch_px<F, O, false>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf); }, {}});
+    std::snprintf(label, sizeof label, "bpx %s records per XCD", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_batch_px<F, O, true>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_perm, ntiles, pf); }, {}});
+    std::snprintf(label, sizeof label, "bpx %s records per XCD, next line touched 1 ahead", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_batch_px<F, O, true, 1>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_perm, ntiles, pf); }, {}});
+    std::snprintf(label, sizeof label, "bpx %s records per XCD, next line touched 4 ahead", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_batch_px<F, O, true, 4>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_perm, ntiles, pf); }, {}});
+    const unsigned grid = (unsigned)ntiles;
+    std::snprintf(label, sizeof label, "bpx %s single-tensor kernel", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, ps); }, {}});
 }
 
 int main(int argc, char **argv) {
@@ -981,6 +1021,12 @@ int main(int argc, char **argv) {
         DDEQ(OutF32, 128, 2, PB32, LB32, "ddeq Q4K f32 thr128 S2")
         SHIP(Q4K, OutF32, "ddeq ref ship Q4K f32")
         SHIP(Q4K, OutF16, "ddeq ref ship Q4K f16")
+    }
+    // ---- tile records laid out per XCD
+    {
+#define BPX(F, O, OT, NAME) add_batch_px<F, O>(vs, NAME, d_in, d_out, elems, prefetch_for(F##_ID, OT, true), prefetch_for(F##_ID, OT, false));
+        BPX(Q4K, OutF32, GGQ_TYPE_F32, "Q4K f32") BPX(Q6K, OutF32, GGQ_TYPE_F32, "Q6K f32") BPX(Q8_0, OutF32, GGQ_TYPE_F32, "Q8_0 f32")
+        BPX(Q4K, OutF16, GGQ_TYPE_F16, "Q4K f16") BPX(Q6K, OutF16, GGQ_TYPE_F16, "Q6K f16") BPX(Q2K, OutF16, GGQ_TYPE_F16, "Q2K f16")
     }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
