@@ -137,3 +137,52 @@ def test_tinyllama_f16_q8_0_round_trip_whole_model(torch_cuda, oracle):
         del w16, q, y
     assert total == 1_099_956_224
     assert worst < 4.5e-3
+
+
+@pytest.mark.parametrize("name,out", [
+    ("llama7b_q4_k_m", "f32"), ("llama7b_q4_k_m", "f16"), ("tinyllama_q4_k_m", "bf16"),
+    ("llama7b_q2_k", "f32"), ("llama7b_q3_k", "f32"), ("llama7b_q5_k", "f32"), ("llama7b_q6_k", "f32"),
+    ("llama7b_q4_0", "f32"), ("llama7b_q8_0", "f32"), ("llama7b_iq4_nl", "f32"), ("llama7b_iq4_xs", "f32"),
+])
+def test_every_element_against_oracle(torch_cuda, oracle, name, out):
+    """Whole tensor sets without sampling: all tensors through one launch plan, and every element (6.7 G per
+    Llama-7B set) compared bit for bit with the CPU oracle's decode of the same packed bytes.  The first entry is
+    the configuration the benchmark's headline is quoted on."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    from gguf_amd.quants import GGmlType, block_elems
+    t = torch_cuda
+    items = synth.workload(name)
+    ob = 4 if out == "f32" else 2
+    pin, pout, elems = synth.workload_bytes(items, ob)
+    if pin + pout + (4 << 30) > t.cuda.mem_get_info()[0]:
+        pytest.skip("not enough free HBM")
+    out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    dst_all = t.empty(elems, dtype=out_dt, device="cuda")
+    if ob == 2:
+        dst_all.view(t.int16).fill_(0x7FC1)
+    else:
+        dst_all.view(t.int32).fill_(0x7FC00001)
+    tensors, at = [], 0
+    for i, (_, ty, ne) in enumerate(items):
+        src = synth.random_blocks_device(ty, ne // block_elems(ty), 0xC0FFEE00 + i, "cuda")
+        tensors.append((ty, src, dst_all[at:at + ne]))
+        at += ne
+    b = g.Batch(tensors, {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out])
+    b.run()
+    t.cuda.synchronize()
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    checked = 0
+    for k, (ty, src, dst) in enumerate(tensors):
+        want = oracle.dequantize(int(ty), src.cpu().numpy(), o_out, threads=16)
+        if ob == 4:
+            got = dst.cpu().numpy().view(np.uint32)
+            want = want.view(np.uint32)
+        else:
+            got = dst.view(t.int16).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, want), (name, out, items[k][0], first_diff(got, want))
+        checked += got.size
+    b.close()
+    assert checked == elems
+    if name.startswith("llama7b"):
+        assert elems == 6_738_149_376
