@@ -187,3 +187,27 @@ def test_tinyllama_f16_to_q8_0_round_trip(torch_cuda, oracle):
     want = oracle.dequantize(8, want_q, threads=8)
     assert same_bits(out.cpu().numpy(), want)
     assert float(np.max(np.abs(want - w16.astype(np.float32)))) < 4.5e-3
+
+
+@pytest.mark.parametrize("ty", QUANT)
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_large_tensor_every_block(torch_cuda, oracle, ty, kind):
+    """32 Mi elements of N(0, 0.02^2) weights (a [4096, 8192] matrix) per encoder and input type: every packed
+    byte against the oracle's quantizer."""
+    import gguf_amd as g
+    t = torch_cuda
+    n = 32 << 20
+    gen = t.Generator(device="cuda")
+    gen.manual_seed(4000 + ty)
+    x = t.randn(n, device="cuda", generator=gen) * 0.02
+    if kind != "f32":
+        x = x.to(t.float16 if kind == "f16" else t.bfloat16)
+    q = t.empty(n // g.block_elems(ty) * g.block_bytes(ty), dtype=t.uint8, device="cuda")
+    g.quantize_slice(ty, q, x)
+    t.cuda.synchronize()
+    host = x.cpu().numpy() if kind == "f32" else x.view(t.int16).cpu().numpy().view(np.uint16)
+    want = oracle.quantize(ty, host, in_ty=IN[kind])
+    got = q.cpu().numpy()
+    if not np.array_equal(got, want):
+        bad = np.nonzero(got != want)[0]
+        raise AssertionError(f"type {ty} from {kind}: {bad.size} bytes differ, first at {int(bad[0])}")
