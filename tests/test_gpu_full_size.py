@@ -143,11 +143,13 @@ def test_tinyllama_f16_q8_0_round_trip_whole_model(torch_cuda, oracle):
     ("llama7b_q4_k_m", "f32"), ("llama7b_q4_k_m", "f16"), ("tinyllama_q4_k_m", "bf16"),
     ("llama7b_q2_k", "f32"), ("llama7b_q3_k", "f32"), ("llama7b_q5_k", "f32"), ("llama7b_q6_k", "f32"),
     ("llama7b_q4_0", "f32"), ("llama7b_q8_0", "f32"), ("llama7b_iq4_nl", "f32"), ("llama7b_iq4_xs", "f32"),
+    ("llama70b_q4_k_m_iq4nl", "f16"),
 ])
 def test_every_element_against_oracle(torch_cuda, oracle, name, out):
     """Whole tensor sets without sampling: all tensors through one launch plan, and every element (6.7 G per
-    Llama-7B set) compared bit for bit with the CPU oracle's decode of the same packed bytes.  The first entry is
-    the configuration the benchmark's headline is quoted on."""
+    Llama-7B set, 69 G for the Llama-70B set) compared bit for bit with the CPU oracle's decode of the same packed
+    bytes, one tensor at a time on the host.  The first entry is the configuration the benchmark's headline is
+    quoted on, the last the streamed one."""
     import gguf_amd as g
     from gguf_amd import synth
     from gguf_amd.quants import GGmlType, block_elems
