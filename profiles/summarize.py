@@ -68,6 +68,8 @@ def main():
     tpath = os.path.join(HERE, "traffic.json")
     doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for k in fe:
+        if "deq_batch<ggq::" not in k and "deq_one<ggq::" not in k and "quant_one<ggq::" not in k:
+            continue        # helper kernels (the tile table builder) carry no format
         fmt = k.split("<ggq::")[1].split(",")[0]
         read_b = 2.0 * fe[k] * 1024.0
         write_b = wr.get(k, 0.0) * 1024.0
