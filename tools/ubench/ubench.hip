@@ -192,6 +192,9 @@ void add_batch_px(std::vector<UbVariant> &vs, const char *name, const uint8_t *d
     vs.push_back({label, bytes, [=](hipStream_t s) {
                       hipLaunchKernelGGL((deq_batch_px<F, O, true, 4>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_perm, ntiles, pf); }, {}});
     const unsigned grid = (unsigned)ntiles;
+    std::snprintf(label, sizeof label, "bpx %s single-tensor kernel, batch schedule", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf); }, {}});
     std::snprintf(label, sizeof label, "bpx %s single-tensor kernel", name);
     vs.push_back({label, bytes, [=](hipStream_t s) {
                       hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, ps); }, {}});
@@ -1027,6 +1030,7 @@ int main(int argc, char **argv) {
 #define BPX(F, O, OT, NAME) add_batch_px<F, O>(vs, NAME, d_in, d_out, elems, prefetch_for(F##_ID, OT, true), prefetch_for(F##_ID, OT, false));
         BPX(Q4K, OutF32, GGQ_TYPE_F32, "Q4K f32") BPX(Q6K, OutF32, GGQ_TYPE_F32, "Q6K f32") BPX(Q8_0, OutF32, GGQ_TYPE_F32, "Q8_0 f32")
         BPX(Q4K, OutF16, GGQ_TYPE_F16, "Q4K f16") BPX(Q6K, OutF16, GGQ_TYPE_F16, "Q6K f16") BPX(Q2K, OutF16, GGQ_TYPE_F16, "Q2K f16")
+        BPX(Q4_0, OutF16, GGQ_TYPE_F16, "Q4_0 f16") BPX(Q5K, OutF16, GGQ_TYPE_F16, "Q5K f16")
     }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
