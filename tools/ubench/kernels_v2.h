@@ -1063,4 +1063,26 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch_px(const TileRef *__rest
     asm volatile("" ::"v"(touch2));
 }
 
+// ---- single-tensor kernel behind a shared wait ------------------------------------------------------------
+// G consecutive workgroups first load one dword of the same line (the first line of the first of their G tiles)
+// and wait for it before they issue their own tile loads: the line arrives at all of them together, so their reads
+// reach the memory bunched.  (The batch kernel does this by accident: the 8 records of a line in tile order.)
+template <class F, class O, uint32_t G>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_gate(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                           uint64_t nblocks, Prefetch pf) {
+    typedef TileGeom<F, O> TG;
+    __shared__ uint4v lds[TG::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * TG::TB;
+    const uint32_t nblk = rem < TG::TB ? (uint32_t)rem : TG::TB;
+    const uint8_t *gate = (const uint8_t *)((uintptr_t)(src + (t / G * G) * TG::TBYTES) & ~(uintptr_t)3);
+    uint32_t gv = *(const uint32_t *)gate, zero;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(gv));
+    const uint32_t z = __builtin_amdgcn_readfirstlane(zero);       // 0, but only known once the gate line is here
+    const uint8_t *line = prefetch_line<TG>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * TG::TB <= nblocks ? src + tt * TG::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * TG::TBYTES + z, nblk, dst + t * TG::ELEMS, line);
+}
+
 }  // namespace ggq

@@ -1032,6 +1032,42 @@ int main(int argc, char **argv) {
         BPX(Q4K, OutF16, GGQ_TYPE_F16, "Q4K f16") BPX(Q6K, OutF16, GGQ_TYPE_F16, "Q6K f16") BPX(Q2K, OutF16, GGQ_TYPE_F16, "Q2K f16")
         BPX(Q4_0, OutF16, GGQ_TYPE_F16, "Q4_0 f16") BPX(Q5K, OutF16, GGQ_TYPE_F16, "Q5K f16")
     }
+    // ---- single-tensor kernel behind a shared wait of G workgroups
+    {
+#define GATE1(F, O, G, PF, LABEL)                                                                              \
+        {                                                                                                      \
+            typedef TileGeom<F, O> TG_;                                                                        \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TG_::TB - 1) / TG_::TB);                                \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            const Prefetch pf_ = PF;                                                                           \
+            vs.push_back({LABEL, bytes, [=](hipStream_t s) {                                                   \
+                              hipLaunchKernelGGL((deq_one_gate<F, O, G>), dim3(grid), dim3(WG_THREADS), 0, s,  \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, pf_); }, {}}); \
+        }
+#define GATES(F, O, OT, NAME)                                                                                  \
+        {                                                                                                      \
+            const Prefetch ps = prefetch_for(F##_ID, OT, false);                                               \
+            GATE1(F, O, 1, ps, "gate " NAME " G1 (own line, shipped schedule)")                               \
+            GATE1(F, O, 8, ps, "gate " NAME " G8 shipped schedule")                                           \
+            GATE1(F, O, 16, ps, "gate " NAME " G16 shipped schedule")                                         \
+            GATE1(F, O, 8, (Prefetch{0, 0}), "gate " NAME " G8 no prefetch")                                  \
+            GATE1(F, O, 16, (Prefetch{0, 0}), "gate " NAME " G16 no prefetch")                                \
+            GATE1(F, O, 32, (Prefetch{0, 0}), "gate " NAME " G32 no prefetch")                                \
+            GATE1(F, O, 64, (Prefetch{0, 0}), "gate " NAME " G64 no prefetch")                                \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            vs.push_back({"gate " NAME " shipped kernel", bytes, [=](hipStream_t s) {                          \
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ps); }, {}}); \
+            vs.push_back({"gate " NAME " shipped kernel, no prefetch", bytes, [=](hipStream_t s) {             \
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, Prefetch{0, 0}); }, {}}); \
+        }
+        GATES(Q6K, OutF16, 1u, "Q6K f16") GATES(Q8_0, OutF16, 1u, "Q8_0 f16") GATES(Q5K, OutF16, 1u, "Q5K f16")
+        GATES(Q4K, OutF16, 1u, "Q4K f16") GATES(Q8_0, OutF32, 0u, "Q8_0 f32") GATES(Q4K, OutF32, 0u, "Q4K f32")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
