@@ -153,6 +153,13 @@ const uint64_t kMaxGrid = [] {
     return lim;
 }();
 
+// GGQ_WIDE_INDEX=1 (environment, read once): take the 64-bit index kernels also for small tensors, so that tests
+// reach them.
+const bool kWideIndex = [] {
+    const char *e = std::getenv("GGQ_WIDE_INDEX");
+    return e && e[0] == '1';
+}();
+
 #define GGQ_FORMATS(X)                                                                      \
     X(GGQ_TYPE_Q4_0, Q4_0) X(GGQ_TYPE_Q4_1, Q4_1) X(GGQ_TYPE_Q5_0, Q5_0) X(GGQ_TYPE_Q5_1, Q5_1) \
     X(GGQ_TYPE_Q8_0, Q8_0) X(GGQ_TYPE_Q8_1, Q8_1) X(GGQ_TYPE_Q2K, Q2K) X(GGQ_TYPE_Q3K, Q3K)     \
@@ -926,13 +933,24 @@ ggq_status ggq_permute_qk_device(uint32_t ty, uint64_t row_elems, uint64_t rows,
     hipStream_t q = (hipStream_t)hip_stream;
     uint8_t *o = (uint8_t *)d_dst;
     const uint8_t *i = (const uint8_t *)d_src;
+    // 32-bit indices when they cannot wrap (then rows, dh and pieces per row fit as well)
+    const bool narrow = pieces <= 0xFFFFFF00ull - STREAM_THREADS && !kWideIndex;
+    const FastDiv32 ppr = FastDiv32::make(narrow ? (uint32_t)(rb / vec) : 1u), dhd = FastDiv32::make(narrow ? (uint32_t)dh : 1u);
     for (uint64_t w0 = 0; w0 < wgs; w0 += kMaxGrid) {
         const dim3 grid((uint32_t)std::min(kMaxGrid, wgs - w0)), wg(STREAM_THREADS);
         const uint64_t first = w0 * per_wg;
-        if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), grid, wg, 0, q, o, i, rb, rows, dh, first);
-        else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), grid, wg, 0, q, o, i, rb, rows, dh, first);
-        else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows<2>), grid, wg, 0, q, o, i, rb, rows, dh, first);
-        else hipLaunchKernelGGL((permute_qk_rows<1>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+        if (narrow) {
+            const uint32_t total = (uint32_t)pieces, f32 = (uint32_t)first;
+            if (vec == 16) hipLaunchKernelGGL((permute_qk_rows<16>), grid, wg, 0, q, o, i, rb, total, ppr, dhd, f32);
+            else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows<4>), grid, wg, 0, q, o, i, rb, total, ppr, dhd, f32);
+            else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows<2>), grid, wg, 0, q, o, i, rb, total, ppr, dhd, f32);
+            else hipLaunchKernelGGL((permute_qk_rows<1>), grid, wg, 0, q, o, i, rb, total, ppr, dhd, f32);
+        } else {
+            if (vec == 16) hipLaunchKernelGGL((permute_qk_rows_wide<16>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+            else if (vec == 4) hipLaunchKernelGGL((permute_qk_rows_wide<4>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+            else if (vec == 2) hipLaunchKernelGGL((permute_qk_rows_wide<2>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+            else hipLaunchKernelGGL((permute_qk_rows_wide<1>), grid, wg, 0, q, o, i, rb, rows, dh, first);
+        }
     }
     HIP_TRY(hipGetLastError());
     return GGQ_OK;

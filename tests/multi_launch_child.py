@@ -82,6 +82,13 @@ src = np.random.default_rng(6).integers(0, 256, 64 * rb, dtype=np.uint8)
 got = R.permute_qk(12, 4096, 64, 4, t.from_numpy(src).cuda())
 t.cuda.synchronize()
 assert np.array_equal(got.cpu().numpy(), np_permute_qk(src, rb, 64, 4)), "permute"
+# and with divisors that are not powers of two: 25 pieces a row (F32 rows of 100), heads of 6 and of 10 rows
+for nh, dh in ((8, 6), (3, 10), (5, 24)):
+    rb = R.row_bytes(0, 100)
+    src = np.random.default_rng(nh).integers(0, 256, nh * dh * rb, dtype=np.uint8)
+    got = R.permute_qk(0, 100, nh * dh, nh, t.from_numpy(src).cuda())
+    t.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), np_permute_qk(src, rb, nh * dh, nh)), ("permute", nh, dh)
 
 # scale: 10 workgroups of 16-byte pieces plus a tail of single elements, aligned and from an odd address
 for ty, npdt in ((0, np.float32), (1, np.uint16), (30, np.uint16), (28, np.float64)):

@@ -11,8 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_split_launch_paths(oracle):
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_split_launch_paths(oracle, wide):
+    """wide = 1 also forces the 64-bit index kernels that tensors of 2^32 pieces and more take."""
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_launch_child.py")
-    env = dict(os.environ, GGQ_MAX_GRID="3")
+    env = dict(os.environ, GGQ_MAX_GRID="3", GGQ_WIDE_INDEX=wide)
     r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])

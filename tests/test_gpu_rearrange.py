@@ -17,7 +17,7 @@ def test_permute_qk(ty, row_elems):
     import torch
     from gguf_amd import rearrange as R
     rb = R.row_bytes(ty, row_elems)
-    for nh, dh in ((32, 128), (4, 64), (1, 2), (8, 6)):
+    for nh, dh in ((32, 128), (4, 64), (1, 2), (8, 6), (3, 10), (7, 14), (5, 96), (2, 250)):
         rows = nh * dh
         src = np.random.default_rng(rows + ty).integers(0, 256, rows * rb, dtype=np.uint8)
         got = R.permute_qk(ty, row_elems, rows, nh, torch.from_numpy(src).cuda())

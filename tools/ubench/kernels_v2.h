@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "rearrange.h"
 
 namespace ggq {
 
@@ -1083,6 +1084,43 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_gate(const uint8_t *__rest
         return (tt + 1) * TG::TB <= nblocks ? src + tt * TG::TBYTES : nullptr;
     });
     deq_tile<F, O, true>(lds, src + t * TG::TBYTES + z, nblk, dst + t * TG::ELEMS, line);
+}
+
+// the same shape as a plain copy: what the gather pattern itself costs
+__global__ __launch_bounds__(STREAM_THREADS) void copy16_flat(uint4v *__restrict__ dst, const uint4v *__restrict__ src, uint64_t total) {
+    const uint64_t p = (uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x;
+    if (p >= total) return;
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + p), dst + p);
+}
+
+// ---- decode kernel whose prefetch phase is computed without a division ---------------------------------------
+template <class G, class SrcOf>
+__device__ __forceinline__ const uint8_t *prefetch_line_fd(uint32_t t, Prefetch pf, FastDiv32 per, SrcOf tile_src) {
+    if (pf.period == 0) return nullptr;
+    const uint32_t ph = t - per.div(t) * pf.period;
+    const uint32_t nb = (pf.period + G::TPW - 1) / G::TPW;
+    if (ph >= nb) return nullptr;
+    const uint32_t j = threadIdx.x / G::LINES, l = threadIdx.x % G::LINES;
+    const uint32_t k = ph * G::TPW + j;
+    if (j >= G::TPW || k >= pf.period) return nullptr;
+    const uint8_t *base = tile_src((uint64_t)t - ph + pf.lead + k);
+    if (base == nullptr) return nullptr;
+    const uint8_t *line = (const uint8_t *)((uintptr_t)base & ~(uintptr_t)127) + 128u * l;
+    return line < base + G::TBYTES ? line : nullptr;
+}
+
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_fd(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                         uint64_t nblocks, Prefetch pf, FastDiv32 per) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint32_t t = blockIdx.x;
+    const uint64_t rem = nblocks - (uint64_t)t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint8_t *line = prefetch_line_fd<G>(t, pf, per, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + (uint64_t)t * G::TBYTES, nblk, dst + (uint64_t)t * G::ELEMS, line);
 }
 
 }  // namespace ggq

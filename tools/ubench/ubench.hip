@@ -602,9 +602,22 @@ int main(int argc, char **argv) {
             const unsigned grid = (unsigned)((pieces + per_wg - 1) / per_wg);
             char label[64];
             std::snprintf(label, sizeof label, "permute_qk rows of %llu bytes", (unsigned long long)rb);
+            const FastDiv32 fp = FastDiv32::make((uint32_t)(rb / 16)), fd = FastDiv32::make((uint32_t)dh);
             vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
                               hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(STREAM_THREADS), 0, s,
+                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, (uint32_t)pieces, fp, fd, 0u); }, {}});
+            std::snprintf(label, sizeof label, "pqk shipped rows of %llu bytes", (unsigned long long)rb);
+            vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((permute_qk_rows<16>), dim3(grid), dim3(STREAM_THREADS), 0, s,
+                                                 (uint8_t *)d_out, (const uint8_t *)d_in, rb, (uint32_t)pieces, fp, fd, 0u); }, {}});
+            std::snprintf(label, sizeof label, "pqk 64-bit index rows of %llu bytes", (unsigned long long)rb);
+            vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((permute_qk_rows_wide<16>), dim3(grid), dim3(STREAM_THREADS), 0, s,
                                                  (uint8_t *)d_out, (const uint8_t *)d_in, rb, rows, dh, (uint64_t)0); }, {}});
+            std::snprintf(label, sizeof label, "pqk plain copy of %llu-byte rows", (unsigned long long)rb);
+            vs.push_back({label, 2.0 * rb * rows, [=](hipStream_t s) {
+                              hipLaunchKernelGGL(copy16_flat, dim3(grid), dim3(STREAM_THREADS), 0, s,
+                                                 (uint4v *)d_out, (const uint4v *)d_in, pieces); }, {}});
         }
     }
     QNT(EncQ4_0, InF32, "quant Q4_0 from f32")
@@ -1067,6 +1080,25 @@ int main(int argc, char **argv) {
         }
         GATES(Q6K, OutF16, 1u, "Q6K f16") GATES(Q8_0, OutF16, 1u, "Q8_0 f16") GATES(Q5K, OutF16, 1u, "Q5K f16")
         GATES(Q4K, OutF16, 1u, "Q4K f16") GATES(Q8_0, OutF32, 0u, "Q8_0 f32") GATES(Q4K, OutF32, 0u, "Q4K f32")
+    }
+    // ---- prefetch phase by multiplication instead of a 64-bit remainder
+    {
+#define PFD(F, O, OT, NAME)                                                                                    \
+        {                                                                                                      \
+            const Prefetch ps = prefetch_for(F##_ID, OT, false);                                               \
+            const FastDiv32 per = FastDiv32::make(ps.period ? ps.period : 1u);                                 \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            vs.push_back({"pfd " NAME " phase by multiplication", bytes, [=](hipStream_t s) {                  \
+                              hipLaunchKernelGGL((deq_one_fd<F, O>), dim3(grid), dim3(WG_THREADS), 0, s,       \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ps, per); }, {}}); \
+            vs.push_back({"pfd " NAME " shipped kernel", bytes, [=](hipStream_t s) {                           \
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ps); }, {}}); \
+        }
+        PFD(Q4K, OutF32, 0u, "Q4K f32") PFD(Q4K, OutF16, 1u, "Q4K f16") PFD(Q3K, OutF16, 1u, "Q3K f16") PFD(Q6K, OutF16, 1u, "Q6K f16")
+        PFD(Q5K, OutF16, 1u, "Q5K f16") PFD(IQ4XS, OutF16, 1u, "IQ4XS f16") PFD(Q6K, OutF32, 0u, "Q6K f32")
     }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
