@@ -6,6 +6,8 @@ properties that do not need the CPU oracle to decode everything:
       block, and the tile table / geometry of the batch places every block's output correctly);
   (b) 4096 random blocks per block type against the oracle, bit for bit.
 """
+import gc
+
 import numpy as np
 import pytest
 
@@ -29,6 +31,8 @@ def run_workload(t, oracle, name, out):
     out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
     ob = 4 if out == "f32" else 2
     pin, pout, elems = synth.workload_bytes(items, ob)
+    gc.collect()
+    t.cuda.empty_cache()             # blocks that earlier tests freed still sit in torch's allocator
     free = t.cuda.mem_get_info()[0]
     if pin + pout + (4 << 30) > free:
         pytest.skip(f"{name} -> {out} needs {(pin + pout) / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} GiB free")
@@ -157,6 +161,8 @@ def test_every_element_against_oracle(torch_cuda, oracle, name, out):
     items = synth.workload(name)
     ob = 4 if out == "f32" else 2
     pin, pout, elems = synth.workload_bytes(items, ob)
+    gc.collect()
+    t.cuda.empty_cache()             # blocks that earlier tests freed still sit in torch's allocator
     if pin + pout + (4 << 30) > t.cuda.mem_get_info()[0]:
         pytest.skip("not enough free HBM")
     out_dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
