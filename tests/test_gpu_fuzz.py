@@ -122,3 +122,62 @@ def test_launch_plan_matches_oracle(oracle, out, plan, seed):
             got = d.view(t.int16).cpu().numpy().view(np.uint16)
             assert same_bits16(got, want, out), (ty, p.size, first_diff(got, want))
     b.close()
+
+
+@settings(**_cfg)
+@given(ty=st.sampled_from([12, 2, 14, 0, 1, 8, 24, 10]), blocks_per_row=st.integers(1, 40), nh=st.integers(1, 9),
+       half=st.integers(1, 70), seed=st.integers(0, 2 ** 31))
+def test_permute_qk_matches_numpy(ty, blocks_per_row, nh, half, seed):
+    """Drawn row sizes (so pieces per row of 16, 4, 2 or 1 bytes, powers of two or not) and head sizes."""
+    import torch
+    from gguf_amd import rearrange as R
+    from gguf_amd._lib import lib
+    from test_gpu_rearrange import np_permute_qk
+    row_elems = blocks_per_row * lib.ggq_gguf_type_elems(ty)
+    rows = nh * 2 * half
+    rb = R.row_bytes(ty, row_elems)
+    src = np.random.default_rng(seed).integers(0, 256, rows * rb, dtype=np.uint8)
+    got = R.permute_qk(ty, row_elems, rows, nh, torch.from_numpy(src).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), np_permute_qk(src, rb, rows, nh)), (ty, row_elems, nh, half)
+
+
+@settings(**_cfg)
+@given(ty=st.sampled_from([0, 1, 30, 28]), n=st.one_of(st.integers(1, 300), st.integers(1000, 200000)),
+       offset=st.integers(0, 7), factor=st.floats(allow_nan=False, allow_infinity=False, width=64),
+       wide=st.booleans(), seed=st.integers(0, 2 ** 31))
+def test_scale_matches_oracle(oracle, ty, n, offset, factor, wide, seed):
+    """Drawn element types, lengths, element-aligned start offsets and f64 factors (any finite double, so the
+    factor's own narrowing to f32 / f16 / bf16 is drawn too), against the oracle's scale_data."""
+    import torch
+    from gguf_amd import rearrange as R
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n)
+    if wide:
+        x *= 10.0 ** rng.integers(-12, 12, n)
+    if ty == 0:
+        host = x.astype(np.float32)
+    elif ty == 28:
+        host = x
+    elif ty == 1:
+        with np.errstate(over="ignore"):
+            host = x.astype(np.float16).view(np.uint16)
+    else:
+        host = (x.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    eb = host.dtype.itemsize
+    want = oracle.scale(ty, host, factor)
+    dev = torch.empty(host.nbytes + 64, dtype=torch.uint8, device="cuda")
+    view = dev[offset * eb:offset * eb + host.nbytes]
+    view.copy_(torch.from_numpy(host.view(np.uint8).copy()))
+    got = R.scale(ty, view, factor).cpu().numpy()
+    w8 = want.view(np.uint8)
+    if not np.array_equal(got, w8):
+        # NaN results (inf * 0) must be NaN on both sides; every other element bit for bit
+        g = got.view(host.dtype if ty in (0, 28) else np.uint16)
+        if ty in (0, 28):
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(g), nan) and np.array_equal(g[~nan].view(np.uint8), want[~nan].view(np.uint8))
+        else:
+            f = (lambda b: b.view(np.float16)) if ty == 1 else (lambda b: (b.astype(np.uint32) << 16).view(np.float32))
+            nan = np.isnan(f(want))
+            assert np.array_equal(np.isnan(f(g)), nan) and np.array_equal(g[~nan], want[~nan])
