@@ -30,7 +30,8 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
             }
         }
         switch (ty) {
-        case GGQ_TYPE_Q4K: return {1536, 2048};
+        case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: return {1536, 2048};
+        case GGQ_TYPE_Q5K: return {1280, 2048};
         case GGQ_TYPE_Q3K: return {1024, 2048};
         case GGQ_TYPE_Q6K: return {1024, 1536};
         case GGQ_TYPE_Q8K: case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: return {1024, 1280};
