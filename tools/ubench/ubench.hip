@@ -1100,6 +1100,24 @@ int main(int argc, char **argv) {
         PFD(Q4K, OutF32, 0u, "Q4K f32") PFD(Q4K, OutF16, 1u, "Q4K f16") PFD(Q3K, OutF16, 1u, "Q3K f16") PFD(Q6K, OutF16, 1u, "Q6K f16")
         PFD(Q5K, OutF16, 1u, "Q5K f16") PFD(IQ4XS, OutF16, 1u, "IQ4XS f16") PFD(Q6K, OutF32, 0u, "Q6K f32")
     }
+    // ---- non-temporal tile loads for formats whose tiles are whole 128-byte lines (aligned source)
+    {
+#define NTLV(F, O, OT, NAME)                                                                                   \
+        {                                                                                                      \
+            const Prefetch ps = prefetch_for(F##_ID, OT, false);                                               \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            vs.push_back({"ntl " NAME " plain loads (shipped)", bytes, [=](hipStream_t s) {                    \
+                              hipLaunchKernelGGL((deq_one<F, O, true, false>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ps); }, {}}); \
+            vs.push_back({"ntl " NAME " non-temporal loads", bytes, [=](hipStream_t s) {                       \
+                              hipLaunchKernelGGL((deq_one<F, O, true, true>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ps); }, {}}); \
+        }
+        NTLV(Q8_0, OutF32, 0u, "Q8_0 f32") NTLV(Q4K, OutF32, 0u, "Q4K f32") NTLV(Q8_0, OutF16, 1u, "Q8_0 f16") NTLV(Q4K, OutF16, 1u, "Q4K f16")
+        NTLV(Q4_0, OutF32, 0u, "Q4_0 f32") NTLV(Q5K, OutF32, 0u, "Q5K f32")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
