@@ -18,44 +18,6 @@
 
 namespace ggq {
 
-// Division of a 32-bit value by a launch constant as a multiply-high and shifts (round-up method: for d not a
-// power of two, l = floor(log2 d) and m = floor(2^(32+l) / d) + 1 when that over-estimates by less than 2^l,
-// else the 33-bit magic whose top bit is applied as an add).  The kernel below divides twice per thread; with
-// the compiler's general 64-bit division that index arithmetic cost 2.5-4.5 % of the gather's speed.
-struct FastDiv32 {
-    uint32_t magic, shift, add, d;
-    __host__ static FastDiv32 make(uint32_t d) {
-        FastDiv32 f{0, 0, 0, d};
-        if ((d & (d - 1)) == 0) {                      // power of two (and d = 1): shift only
-            while ((1u << f.shift) < d) ++f.shift;
-            return f;
-        }
-        uint32_t l = 31;
-        while (!((d >> l) & 1u)) --l;
-        const uint64_t two = 1ull << (32 + l);
-        uint64_t m = two / d;
-        const uint64_t rem = two - m * d;
-        f.shift = l;
-        if (d - rem < (1ull << l)) {
-            f.magic = (uint32_t)(m + 1);
-        } else {
-            m = 2 * m + (2 * rem >= d ? 1 : 0);
-            f.magic = (uint32_t)(m + 1);
-            f.add = 1;
-        }
-        return f;
-    }
-    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
-        if (magic == 0) return n >> shift;
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t q = __umulhi(n, magic);
-#else
-        const uint32_t q = (uint32_t)(((uint64_t)n * magic) >> 32);
-#endif
-        return add ? (((n - q) >> 1) + q) >> shift : q >> shift;
-    }
-};
-
 // dst row i <- src row perm(i); VEC = bytes per piece: the widest of 16, 4, 2, 1 that divides both addresses and the row size
 template <uint32_t VEC>
 __device__ __forceinline__ void move_piece(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t to, uint64_t from) {

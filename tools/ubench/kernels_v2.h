@@ -693,7 +693,7 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_tab(const uint8_t *__restr
     const uint64_t t = blockIdx.x;
     const uint64_t rem = nblocks - t * G::TB;
     const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+    const uint8_t *line = prefetch_line<G, false>(t, pf, [&](uint64_t tt) -> const uint8_t * {
         return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
     });
     const uint8_t *ts = src + t * G::TBYTES;
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch_px(const TileRef *__rest
     uint32_t touch2 = 0;
     if (AHEAD > 0 && ((t >> 3) & 7) == 0 && threadIdx.x == 0 && t + 64ull * AHEAD < ntiles)
         touch2 = *(const uint32_t *)&table[xcd_slot(t + 64ull * AHEAD)];
-    const uint8_t *line = prefetch_line<G>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+    const uint8_t *line = prefetch_line<G, false>(t, pf, [&](uint64_t tt) -> const uint8_t * {
         if (tt >= ntiles) return nullptr;
         const uint64_t far = table[PERM ? xcd_slot(tt) : tt].src_nblk;
         return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_gate(const uint8_t *__rest
     uint32_t gv = *(const uint32_t *)gate, zero;
     asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(gv));
     const uint32_t z = __builtin_amdgcn_readfirstlane(zero);       // 0, but only known once the gate line is here
-    const uint8_t *line = prefetch_line<TG>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+    const uint8_t *line = prefetch_line<TG, false>(t, pf, [&](uint64_t tt) -> const uint8_t * {
         return (tt + 1) * TG::TB <= nblocks ? src + tt * TG::TBYTES : nullptr;
     });
     deq_tile<F, O, true>(lds, src + t * TG::TBYTES + z, nblk, dst + t * TG::ELEMS, line);
@@ -1114,13 +1114,13 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_fd(const uint8_t *__restri
                                                          uint64_t nblocks, Prefetch pf, FastDiv32 per) {
     typedef TileGeom<F, O> G;
     __shared__ uint4v lds[G::LDS_SLOTS];
-    const uint32_t t = blockIdx.x;
-    const uint64_t rem = nblocks - (uint64_t)t * G::TB;
+    const uint64_t t = blockIdx.x;                 // addresses as in the shipped kernel; only the phase changes
+    const uint64_t rem = nblocks - t * G::TB;
     const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-    const uint8_t *line = prefetch_line_fd<G>(t, pf, per, [&](uint64_t tt) -> const uint8_t * {
+    const uint8_t *line = prefetch_line_fd<G>((uint32_t)t, pf, per, [&](uint64_t tt) -> const uint8_t * {
         return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
     });
-    deq_tile<F, O, true>(lds, src + (uint64_t)t * G::TBYTES, nblk, dst + (uint64_t)t * G::ELEMS, line);
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, line);
 }
 
 }  // namespace ggq

@@ -1099,6 +1099,8 @@ int main(int argc, char **argv) {
         }
         PFD(Q4K, OutF32, 0u, "Q4K f32") PFD(Q4K, OutF16, 1u, "Q4K f16") PFD(Q3K, OutF16, 1u, "Q3K f16") PFD(Q6K, OutF16, 1u, "Q6K f16")
         PFD(Q5K, OutF16, 1u, "Q5K f16") PFD(IQ4XS, OutF16, 1u, "IQ4XS f16") PFD(Q6K, OutF32, 0u, "Q6K f32")
+        PFD(IQ4NL, OutF16, 1u, "IQ4NL f16") PFD(Q2K, OutF16, 1u, "Q2K f16") PFD(Q4_0, OutF16, 1u, "Q4_0 f16") PFD(Q3K, OutF32, 0u, "Q3K f32")
+        PFD(IQ4XS, OutF32, 0u, "IQ4XS f32")
     }
     // ---- non-temporal tile loads for formats whose tiles are whole 128-byte lines (aligned source)
     {
