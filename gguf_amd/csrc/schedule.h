@@ -21,11 +21,9 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
             case GGQ_TYPE_Q2K: return {1280, 2048};
             case GGQ_TYPE_Q3K: return {1024, 1536};
             case GGQ_TYPE_Q4K: return {768, 1536};
-            case GGQ_TYPE_IQ4XS: return {1280, 1536};
             case GGQ_TYPE_Q5K: return {1, 1280};
-            case GGQ_TYPE_IQ4NL: return {384, 1536};
+            case GGQ_TYPE_IQ4NL: case GGQ_TYPE_IQ4XS: return {384, 1536};
             case GGQ_TYPE_Q4_0: return {1024, 1280};
-            case GGQ_TYPE_Q4_1: return {384, 1280};
             default: return {0, 0};
             }
         }

@@ -1205,6 +1205,7 @@ int main(int argc, char **argv) {
         SWB(Q8_0, OutF32, "Q8_0_f32") SWB(Q8_1, OutF32, "Q8_1_f32")
         SWB(Q4K, OutF16, "Q4K_f16") SWB(Q6K, OutF16, "Q6K_f16") SWB(Q8_0, OutF16, "Q8_0_f16") SWB(Q4_0, OutF16, "Q4_0_f16")
         SWB(Q2K, OutF16, "Q2K_f16") SWB(Q5K, OutF16, "Q5K_f16") SWB(Q3K, OutF16, "Q3K_f16")
+        SWB(Q5_1, OutF16, "Q5_1_f16") SWB(Q4_1, OutF16, "Q4_1_f16") SWB(IQ4XS, OutF16, "IQ4XS_f16") SWB(Q5_0, OutF16, "Q5_0_f16")
     }
     if (argc > 3) {
         std::vector<Variant> keep;
