@@ -42,8 +42,8 @@ constexpr bool kNT = GGQ_NT_STORES != 0;
 
 thread_local std::string g_err;
 
-// Measurement knobs, read once: GGQ_NO_PREFETCH=1 switches the burst prefetch off,
-// GGQ_PREFETCH="period,lead" replaces the schedule of every kernel.
+// Measurement knobs, read once: GGQ_NO_PREFETCH=1 switches the burst prefetch and the group start off,
+// GGQ_PREFETCH="period,lead[,wait]" replaces the schedule of every kernel.
 Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
     static const int mode = [] {
         const char *e = std::getenv("GGQ_NO_PREFETCH");
@@ -52,9 +52,9 @@ Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
         return e && *e ? 2 : 0;
     }();
     static const Prefetch forced = [] {
-        Prefetch p{0, 0};
-        if (const char *e = std::getenv("GGQ_PREFETCH")) std::sscanf(e, "%u,%u", &p.period, &p.lead);
-        return p;
+        unsigned period = 0, lead = 0, wait = 0;
+        if (const char *e = std::getenv("GGQ_PREFETCH")) std::sscanf(e, "%u,%u,%u", &period, &lead, &wait);
+        return Prefetch{period, lead, wait > 16 ? 0u : wait};     // built through the constructor: it derives the divisor
     }();
     if (mode == 1) return Prefetch{0, 0};
     if (mode == 2) return forced;

@@ -131,9 +131,26 @@ struct FastDiv32 {
 struct Prefetch {
     uint32_t period;   // a burst of reads is issued once every `period` workgroups
     uint32_t lead;     // ... for the tiles `lead` workgroups ahead of the burst's first workgroup
+    uint32_t wait;     // k > 0: groups of 2^k consecutive workgroups start together (group_wait below); 0: off
     FastDiv32 per;     // `period` as a divisor (made on the host)
-    __host__ Prefetch(uint32_t p = 0, uint32_t l = 0) : period(p), lead(l), per(FastDiv32::make(p)) {}
+    __host__ Prefetch(uint32_t p = 0, uint32_t l = 0, uint32_t w = 0) : period(p), lead(l), wait(w), per(FastDiv32::make(p)) {}
 };
+
+// Group start.  The workgroups of tiles [g, g + 2^k) all load one dword of the line where tile g's OUTPUT begins --
+// memory that is about to be overwritten, so the line is cold and the load takes a full trip to HBM -- and do not
+// issue their tile loads before it is back.  The line returns to all of them at about the same time, so the group
+// reads its 30-100 KB of packed input together and then writes its 128 KB - 1 MB of contiguous output together,
+// instead of eight XCDs drifting apart over the tensor.  The value is not used: it is reduced to a zero that the
+// compiler cannot see through and added to the source address, which is what makes the tile loads wait.
+// This is the alternative to the burst prefetch for streams with a larger share of reads: with the packed input
+// at 21 % of the traffic and more (every 2-byte output except Q2_K and Q3_K; the 8-bit formats with 4-byte
+// output) it beats the burst by 2-7 %, below that it loses by 4-17 % (measurements at schedule.h).
+__device__ __forceinline__ uint32_t group_wait(const void *group_dst) {
+    const uint32_t seen = *(const uint32_t *)group_dst;
+    uint32_t zero;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(seen));
+    return __builtin_amdgcn_readfirstlane(zero);
+}
 
 template <class F, class O>
 struct TileGeom {
@@ -300,10 +317,11 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one(const uint8_t *__restrict_
     const uint64_t t = blockIdx.x;
     const uint64_t rem = nblocks - t * G::TB;
     const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t z = pf.wait ? group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
     const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
         return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;   // whole tiles inside the tensor
     });
-    deq_tile<F, O, NT, NTL>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, line);
+    deq_tile<F, O, NT, NTL>(lds, src + t * G::TBYTES + z, nblk, dst + t * G::ELEMS, line);
 }
 
 // ---- many tensors per launch: workgroup b decodes tile tile0 + b of the group --------
@@ -319,13 +337,15 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch(const TileRef *__restric
     __shared__ uint4v lds[G::LDS_SLOTS];
     const uint64_t t = tile0 + blockIdx.x;
     const TileRef me = table[record_slot<PX>(t)];
+    // the group's first tile may belong to another tensor than this one: its output line is as cold as any
+    const uint32_t z = pf.wait ? group_wait((const void *)table[record_slot<PX>((t >> pf.wait) << pf.wait)].dst) : 0u;
     const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
         if (tt >= ntiles) return nullptr;
         const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
         // whole tiles only (a short tile is a tensor's last one)
         return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
     });
-    deq_tile<F, O, NT>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint32_t)(me.src_nblk >> 48),
+    deq_tile<F, O, NT>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull) + z, (uint32_t)(me.src_nblk >> 48),
                        (typename O::T *)me.dst, line);
 }
 

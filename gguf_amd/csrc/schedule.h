@@ -13,6 +13,7 @@ namespace ggq {
 // 5-6 %).  With 2-byte output the reads are a larger share of the traffic; bunching them gains
 // 2-20 % for the 2- to 5-bit formats and costs 3-7 % for the 8-bit ones, where it stays off.
 // period 1 = every workgroup touches its own tile `lead` ahead (no burst).
+// A third field k > 0 switches the group start on (groups of 2^k workgroups).
 inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
     const bool wide = out_ty == GGQ_TYPE_F32;
     if (batch) {
@@ -36,15 +37,25 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
         default: return {1280, 1536};
         }
     }
+    // Single-tensor kernel.  Where the packed input is a fifth of the traffic or more -- every 2-byte output except
+    // Q2_K and Q3_K, and the 8-bit formats with 4-byte output -- the group start (third field: groups of 2^k
+    // workgroups, see group_wait in kernels.h) replaces the burst; {1, lead} then lets every workgroup touch its
+    // own tile `lead` ahead.  Measured against the burst schedules they replace (`ubench 1024 7 gw <fmt>`, 3 and 30
+    // launches per sample, % of 8 TB/s): Q8_0 -> f32 83.9 / 84.0 against 81.1 / 81.2, Q8_1 84.6 against 81.1, Q8K
+    // 84.5 against 80.7; -> f16: Q4_K 83.0 / 82.7 against 80.5, Q6_K 85.9 / 85.1 against 77.9 / 78.3, Q5_K 84.5 /
+    // 83.4 against 78.5, Q8K 83.5 / 84.0 against 77.0, IQ4_XS 81.7 / 80.8 against 80.7 / 79.4, IQ4_NL 83.3 against
+    // 80.8, Q4_0 83.4 / 83.6 against 80.6 / 80.9, Q4_1 84.3 against 79.3, Q5_0 85.1 against 78.3, Q5_1 85.3 against
+    // 79.0, Q8_0 83.6 against 77.2, Q8_1 83.9 against 76.6.  With a smaller share of reads the burst wins by 4-17 %.
+    // The batch kernel does not take it: with the table's record loads in the stream the same wait LOSES 3-18 %.
     if (!wide) {
         switch (ty) {
         case GGQ_TYPE_Q2K: return {640, 1280};
-        case GGQ_TYPE_Q3K: case GGQ_TYPE_Q5K: case GGQ_TYPE_IQ4XS: case GGQ_TYPE_Q5_0: return {1024, 1024};
-        case GGQ_TYPE_Q4K: return {768, 1280};
-        case GGQ_TYPE_Q6K: return {512, 768};
-        case GGQ_TYPE_Q4_0: case GGQ_TYPE_IQ4NL: return {768, 1024};
-        case GGQ_TYPE_Q4_1: return {384, 1024};
-        default: return {0, 0};
+        case GGQ_TYPE_Q3K: return {1024, 1024};
+        case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: case GGQ_TYPE_IQ4NL: case GGQ_TYPE_Q4_0: return {1, 2048, 6};
+        case GGQ_TYPE_Q5K: return {1, 1280, 6};
+        case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: return {1, 1280, 5};
+        case GGQ_TYPE_Q6K: case GGQ_TYPE_Q5_1: return {1, 1280, 4};
+        default: return {0, 0, 3};                               // Q8_0, Q8_1, Q8K
         }
     }
     switch (ty) {
@@ -53,6 +64,7 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
     case GGQ_TYPE_Q5K: return {640, 1280};
     case GGQ_TYPE_Q6K: return {1024, 1024};
     case GGQ_TYPE_Q4_1: return {512, 1280};
+    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: case GGQ_TYPE_Q8K: return {0, 0, 5};
     default: return {640, 1024};
     }
 }

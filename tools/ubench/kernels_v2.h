@@ -934,7 +934,9 @@ __global__ __launch_bounds__(THR) void deq_one_s(const uint8_t *__restrict__ src
         }
     }
     const uint8_t *ts = src + t * G::TBYTES;
-    typename O::T *out = dst + t * G::ELEMS;
+    // group wait (pf.wait), holding back the stores only
+    const uint32_t z = pf.wait ? group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
+    typename O::T *out = dst + t * G::ELEMS + z;
     const uint32_t off0 = (uint32_t)((uintptr_t)ts & 15u);
     const uint4v *base16 = (const uint4v *)(ts - off0);
     const uint32_t nslots = (off0 + nblk * F::BYTES + 15u) >> 4;
@@ -1121,6 +1123,154 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_fd(const uint8_t *__restri
         return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
     });
     deq_tile<F, O, true>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, line);
+}
+
+// ---- single-tensor kernel that first waits for a cold record, as the batch kernel does ---------------------------
+// MODE 0: a 16-byte record per tile in tile order (what deq_batch reads), value ignored.
+// MODE 1: one dword of the destination line where this group of 8 tiles' output starts (cold, about to be overwritten).
+template <class F, class O, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_rec(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                          uint64_t nblocks, Prefetch pf, const TileRef *__restrict__ table) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    uint32_t probe;
+    if (MODE == 0) probe = (uint32_t)table[t].dst;
+    else probe = *(const uint32_t *)(dst + (t / 8 * 8) * G::ELEMS);
+    uint32_t zero;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(probe));
+    const uint32_t z = __builtin_amdgcn_readfirstlane(zero);
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES + z, nblk, dst + t * G::ELEMS, line);
+}
+
+// ---- single-tensor kernel that first waits for one dword of its group's (cold) destination -------------------------
+// `gshift`: log2 of the group size in tiles; the probed line is where the group's output starts.
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_cdw(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                          uint64_t nblocks, Prefetch pf, uint32_t gshift) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint32_t probe = *(const uint32_t *)(dst + ((t >> gshift) << gshift) * G::ELEMS);
+    uint32_t zero;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(probe));
+    const uint32_t z = __builtin_amdgcn_readfirstlane(zero);
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES + z, nblk, dst + t * G::ELEMS, line);
+}
+
+// ---- group wait that holds back the STORES only (tile loads go out at once) -----------------------------------------
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_late(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                           uint64_t nblocks, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t z = group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS);
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS + z, line);
+}
+
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_late(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf, uint32_t tile_out_bytes) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const TileRef me = table[record_slot<PX>(t)];
+    // bits 48..55 of dst: tiles since the tensor's first tile, clamped to 255 (the host writes it)
+    const uint64_t dstp = me.dst & 0xFFFFFFFFFFFFull;
+    const uint32_t since = (uint32_t)(me.dst >> 48) & 0xFFu;
+    const uint32_t back = min((uint32_t)(t - ((t >> pf.wait) << pf.wait)), since);
+    const uint32_t z = group_wait((const void *)(dstp - (uint64_t)back * tile_out_bytes));
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)(dstp + z), line);
+}
+// the same with the tile loads held back as well (the wait before the loads, dst from the own record)
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_early(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf, uint32_t tile_out_bytes) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const TileRef me = table[record_slot<PX>(t)];
+    const uint64_t dstp = me.dst & 0xFFFFFFFFFFFFull;
+    const uint32_t since = (uint32_t)(me.dst >> 48) & 0xFFu;
+    const uint32_t back = min((uint32_t)(t - ((t >> pf.wait) << pf.wait)), since);
+    const uint32_t z = group_wait((const void *)(dstp - (uint64_t)back * tile_out_bytes));
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull) + z, (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)dstp, line);
+}
+
+// ---- batch kernel, stores held back by a probe whose address comes from a side array (one entry per group) -----------
+// The probe starts together with the record load, so the workgroup does not live longer than today.
+template <class F, class O, bool EARLY>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_side(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf,
+                                                             const uint64_t *__restrict__ group_dst) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t gd = group_dst[t >> pf.wait];
+    const TileRef me = table[record_slot<PX>(t)];
+    const uint32_t z = group_wait((const void *)gd);
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull) + (EARLY ? z : 0u), (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)(me.dst + (EARLY ? 0u : z)), line);
+}
+
+// ---- what breaks the group wait in the batch kernel?  The single-tensor kernel with a record load added. -----------
+// MODE 0: the record is loaded and its value folded into the source address (the tile loads wait for it, as in the
+// batch kernel).  MODE 1: the record is loaded and only kept alive (nothing waits for it until the end).
+template <class F, class O, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_wait_rec(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                               uint64_t nblocks, Prefetch pf, const TileRef *__restrict__ table) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint32_t rec = (uint32_t)table[record_slot<PX>(t)].dst;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t z = pf.wait ? group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
+    uint32_t zr = 0;
+    if (MODE == 0) {
+        uint32_t zero;
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(rec));
+        zr = __builtin_amdgcn_readfirstlane(zero);
+    }
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES + z + zr, nblk, dst + t * G::ELEMS, line);
+    if (MODE == 1) asm volatile("" ::"s"(rec));
 }
 
 }  // namespace ggq

@@ -192,12 +192,117 @@ void add_batch_px(std::vector<UbVariant> &vs, const char *name, const uint8_t *d
     vs.push_back({label, bytes, [=](hipStream_t s) {
                       hipLaunchKernelGGL((deq_batch_px<F, O, true, 4>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_perm, ntiles, pf); }, {}});
     const unsigned grid = (unsigned)ntiles;
+    std::snprintf(label, sizeof label, "bpx %s single-tensor kernel + cold record wait, batch schedule", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_one_rec<F, O, 0>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
+    std::snprintf(label, sizeof label, "bpx %s single-tensor kernel + cold dst line wait, batch schedule", name);
+    vs.push_back({label, bytes, [=](hipStream_t s) {
+                      hipLaunchKernelGGL((deq_one_rec<F, O, 1>), dim3((unsigned)ntiles), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
     std::snprintf(label, sizeof label, "bpx %s single-tensor kernel, batch schedule", name);
     vs.push_back({label, bytes, [=](hipStream_t s) {
                       hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf); }, {}});
     std::snprintf(label, sizeof label, "bpx %s single-tensor kernel", name);
     vs.push_back({label, bytes, [=](hipStream_t s) {
                       hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, ps); }, {}});
+}
+
+// group wait (Prefetch::wait) sweep: single-tensor and batch kernel, wait groups of 4..64 with no burst, against the shipped schedule
+template <class F, class O>
+void add_group_wait(std::vector<UbVariant> &vs, const char *name, uint32_t ty, uint32_t out_ty, const uint8_t *d_in, void *d_out, uint64_t elems) {
+    typedef TileGeom<F, O> G;
+    const uint64_t blocks = elems / F::N;
+    const uint64_t ntiles = (blocks + G::TB - 1) / G::TB;
+    const uint64_t slots = (ntiles + 63) / 64 * 64;
+    std::vector<TileRef> tab(slots);
+    for (uint64_t t = 0; t < ntiles; ++t) {
+        uint64_t nblk = std::min<uint64_t>(G::TB, blocks - t * G::TB);
+        tab[record_slot<RecordOrder<O>::PER_XCD>(t)] = {((uint64_t)(uintptr_t)d_in + t * G::TBYTES) | (nblk << 48),
+                                                        (uint64_t)(uintptr_t)d_out + t * G::ELEMS * sizeof(typename O::T)};
+    }
+    TileRef *d_tab;
+    CK(hipMalloc(&d_tab, slots * sizeof(TileRef)));
+    CK(hipMemcpy(d_tab, tab.data(), slots * sizeof(TileRef), hipMemcpyHostToDevice));
+    std::vector<TileRef> tab2(tab);
+    for (uint64_t t = 0; t < ntiles; ++t)
+        tab2[record_slot<RecordOrder<O>::PER_XCD>(t)].dst |= (uint64_t)std::min<uint64_t>(t, 255) << 48;
+    TileRef *d_tab2;
+    CK(hipMalloc(&d_tab2, slots * sizeof(TileRef)));
+    CK(hipMemcpy(d_tab2, tab2.data(), slots * sizeof(TileRef), hipMemcpyHostToDevice));
+    const uint32_t tob = (uint32_t)(G::ELEMS * sizeof(typename O::T));
+    const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
+    const unsigned grid = (unsigned)ntiles;
+    auto add_late = [&](const char *kind, const char *what, Prefetch pf, int mode) {
+        char label[112];
+        std::snprintf(label, sizeof label, "gw %s %s %s", name, kind, what);
+        if (mode == 0)
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_one_late<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf); }, {}});
+        else if (mode == 1)
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_late<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab2, ntiles, pf, tob); }, {}});
+        else
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_early<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab2, ntiles, pf, tob); }, {}});
+    };
+    for (uint32_t w : {0u, 3u, 5u})
+        for (int mode = 0; mode < 2; ++mode) {
+            char label[112];
+            const Prefetch pf{0, 0, w};
+            std::snprintf(label, sizeof label, "gw %s single+record-%s W%u off", name, mode ? "unused" : "waited", w ? 1u << w : 0u);
+            if (mode == 0)
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_one_wait_rec<F, O, 0>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
+            else
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_one_wait_rec<F, O, 1>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
+        }
+    for (uint32_t w : {3u, 4u, 5u, 6u}) {
+        const uint64_t ng = (ntiles >> w) + 1;
+        std::vector<uint64_t> gd(ng);
+        for (uint64_t g = 0; g < ng; ++g) gd[g] = (uint64_t)(uintptr_t)d_out + std::min<uint64_t>(g << w, ntiles - 1) * tob;
+        uint64_t *d_gd;
+        CK(hipMalloc(&d_gd, ng * 8));
+        CK(hipMemcpy(d_gd, gd.data(), ng * 8, hipMemcpyHostToDevice));
+        for (uint32_t l : {0u, 1280u}) {
+            char label[112];
+            const Prefetch pf = l ? Prefetch{1, l, w} : Prefetch{0, 0, w};
+            std::snprintf(label, sizeof label, "gw %s batch-side-late W%u %s%u", name, 1u << w, l ? "P1 L" : "off ", l);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_side<F, O, false>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf, d_gd); }, {}});
+            std::snprintf(label, sizeof label, "gw %s batch-side-early W%u %s%u", name, 1u << w, l ? "P1 L" : "off ", l);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_side<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf, d_gd); }, {}});
+        }
+    }
+    for (uint32_t w : {3u, 4u, 5u, 6u})
+        for (uint32_t l : {0u, 1280u}) {
+            char what[48];
+            std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
+            const Prefetch pf = l ? Prefetch{1, l, w} : Prefetch{0, 0, w};
+            add_late("single-late", what, pf, 0);
+            add_late("batch-late", what, pf, 1);
+            add_late("batch-early", what, pf, 2);
+        }
+    auto add = [&](const char *kind, const char *what, Prefetch pf, bool batch) {
+        char label[112];
+        std::snprintf(label, sizeof label, "gw %s %s %s", name, kind, what);
+        if (batch)
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, (uint64_t)0, ntiles, pf); }, {}});
+        else
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf); }, {}});
+    };
+    for (int batch = 0; batch < 2; ++batch) {
+        const char *kind = batch ? "batch" : "single";
+        add(kind, "shipped", prefetch_for(ty, out_ty, batch != 0), batch != 0);
+        for (uint32_t w : {2u, 3u, 4u, 5u, 6u})
+            for (uint32_t l : {0u, 512u, 1280u, 2048u}) {
+                char what[48];
+                std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
+                add(kind, what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w}, batch != 0);
+            }
+    }
 }
 
 int main(int argc, char **argv) {
@@ -1120,6 +1225,81 @@ int main(int argc, char **argv) {
         NTLV(Q8_0, OutF32, 0u, "Q8_0 f32") NTLV(Q4K, OutF32, 0u, "Q4K f32") NTLV(Q8_0, OutF16, 1u, "Q8_0 f16") NTLV(Q4K, OutF16, 1u, "Q4K f16")
         NTLV(Q4_0, OutF32, 0u, "Q4_0 f32") NTLV(Q5K, OutF32, 0u, "Q5K f32")
     }
+    // ---- wait for a cold destination line first (formats without a burst schedule)
+    {
+#define CDW(F, O, OT, NAME)                                                                                    \
+        {                                                                                                      \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            const Prefetch ship = prefetch_for(F##_ID, OT, false);                                             \
+            struct { const char *n; Prefetch p; } pfs[] = {{"off", Prefetch{0, 0}}, {"P1 L1280", Prefetch{1, 1280}}, {"shipped", ship}}; \
+            for (auto &pp : pfs) {                                                                             \
+                const Prefetch pf_ = pp.p;                                                                     \
+                char label[96];                                                                                \
+                std::snprintf(label, sizeof label, "cdw %s plain kernel, prefetch %s", NAME, pp.n);            \
+                vs.push_back({label, bytes, [=](hipStream_t s) {                                               \
+                                  hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                     (const uint8_t *)d_in, (typename O::T *)d_out, blocks, pf_); }, {}}); \
+                for (uint32_t gs : {0u, 2u, 3u, 4u, 6u}) {                                                     \
+                    std::snprintf(label, sizeof label, "cdw %s group %u, prefetch %s", NAME, 1u << gs, pp.n);  \
+                    vs.push_back({label, bytes, [=](hipStream_t s) {                                           \
+                                      hipLaunchKernelGGL((deq_one_cdw<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                         (const uint8_t *)d_in, (typename O::T *)d_out, blocks, pf_, gs); }, {}}); \
+                }                                                                                              \
+            }                                                                                                  \
+        }
+        CDW(Q6K, OutF16, 1u, "Q6K f16") CDW(Q5K, OutF16, 1u, "Q5K f16") CDW(Q8_0, OutF16, 1u, "Q8_0 f16") CDW(Q5_1, OutF16, 1u, "Q5_1 f16")
+        CDW(Q8_0, OutF32, 0u, "Q8_0 f32") CDW(Q6K, OutF32, 0u, "Q6K f32") CDW(Q4K, OutF16, 1u, "Q4K f16")
+    }
+    // ---- the same over every format: shipped kernel against the wait with groups of 8 / 16 / 64 and no burst
+    {
+#define CDA(F, O, OT, NAME)                                                                                    \
+        {                                                                                                      \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            const Prefetch ship = prefetch_for(F##_ID, OT, false);                                             \
+            vs.push_back({"cda " NAME " shipped", bytes, [=](hipStream_t s) {                                  \
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ship); }, {}}); \
+            struct { const char *n; Prefetch p; } pfs[] = {{"off", Prefetch{0, 0}}, {"P1 L1280", Prefetch{1, 1280}}}; \
+            for (auto &pp : pfs)                                                                               \
+                for (uint32_t gs : {3u, 4u, 6u}) {                                                             \
+                    const Prefetch pf_ = pp.p;                                                                 \
+                    char label[96];                                                                            \
+                    std::snprintf(label, sizeof label, "cda %s wait group %u, %s", NAME, 1u << gs, pp.n);      \
+                    vs.push_back({label, bytes, [=](hipStream_t s) {                                           \
+                                      hipLaunchKernelGGL((deq_one_cdw<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                         (const uint8_t *)d_in, (typename O::T *)d_out, blocks, pf_, gs); }, {}}); \
+                }                                                                                              \
+        }
+#define CDA2(F, NAME) CDA(F, OutF32, 0u, NAME " f32") CDA(F, OutF16, 1u, NAME " f16")
+        CDA2(Q4K, "Q4K") CDA2(Q6K, "Q6K") CDA2(Q2K, "Q2K") CDA2(Q3K, "Q3K") CDA2(Q5K, "Q5K") CDA2(Q8K, "Q8K") CDA2(IQ4XS, "IQ4XS")
+        CDA2(IQ4NL, "IQ4NL") CDA2(Q4_0, "Q4_0") CDA2(Q4_1, "Q4_1") CDA2(Q5_0, "Q5_0") CDA2(Q5_1, "Q5_1") CDA2(Q8_0, "Q8_0") CDA2(Q8_1, "Q8_1")
+    }
+    // ---- group wait with more bytes in flight per workgroup (more stores per thread)
+    {
+#define SWT(F, O, THR, S, NAME)                                                                                 \
+        {                                                                                                       \
+            typedef SGeom<F, O, THR, S> G;                                                                      \
+            const uint64_t blocks = elems / F::N;                                                               \
+            const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);                                     \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));             \
+            for (uint32_t w : {0u, 2u, 3u, 4u, 5u})                                                             \
+                for (uint32_t l : {0u, 1280u}) {                                                                \
+                    const uint32_t L = l * 2 / S;   /* the same distance in bytes whatever the tile size */    \
+                    const Prefetch pf = l ? Prefetch{1, L, w} : Prefetch{0, 0, w};                              \
+                    char label[112];                                                                            \
+                    std::snprintf(label, sizeof label, "mbf %s thr%d S%d W%u %s", NAME, THR, S, w ? 1u << w : 0u, l ? "P1" : "off"); \
+                    vs.push_back({label, bytes, [=](hipStream_t s) {                                            \
+                                      hipLaunchKernelGGL((deq_one_s<F, O, THR, S>), dim3(grid), dim3(THR), 0, s, \
+                                                         (const uint8_t *)d_in, (typename O::T *)d_out, blocks, pf); }, {}}); \
+                }                                                                                               \
+        }
+#define SWTS(F, O, NAME) SWT(F, O, 512, 2, NAME) SWT(F, O, 512, 4, NAME) SWT(F, O, 256, 4, NAME) SWT(F, O, 256, 8, NAME) SWT(F, O, 512, 3, NAME)
+        SWTS(Q6K, OutF16, "Q6K f16") SWTS(Q8_0, OutF32, "Q8_0 f32") SWTS(Q4K, OutF16, "Q4K f16") SWTS(Q4K, OutF32, "Q4K f32")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
@@ -1206,6 +1386,14 @@ int main(int argc, char **argv) {
         SWB(Q4K, OutF16, "Q4K_f16") SWB(Q6K, OutF16, "Q6K_f16") SWB(Q8_0, OutF16, "Q8_0_f16") SWB(Q4_0, OutF16, "Q4_0_f16")
         SWB(Q2K, OutF16, "Q2K_f16") SWB(Q5K, OutF16, "Q5K_f16") SWB(Q3K, OutF16, "Q3K_f16")
         SWB(Q5_1, OutF16, "Q5_1_f16") SWB(Q4_1, OutF16, "Q4_1_f16") SWB(IQ4XS, OutF16, "IQ4XS_f16") SWB(Q5_0, OutF16, "Q5_0_f16")
+    }
+    if (argc > 4 && std::strcmp(argv[3], "gw") == 0) {     // ubench <Mi> <rounds> gw <FMT>_<f32|f16>
+        vs.clear();
+        std::string f = argv[4];
+#define GW(F, NAME) if (f == NAME "_f32") add_group_wait<F, OutF32>(vs, NAME "_f32", F##_ID, 0u, d_in, d_out, elems); \
+                    if (f == NAME "_f16") add_group_wait<F, OutF16>(vs, NAME "_f16", F##_ID, 1u, d_in, d_out, elems);
+        GW(Q4K, "Q4K") GW(Q6K, "Q6K") GW(Q2K, "Q2K") GW(Q3K, "Q3K") GW(Q5K, "Q5K") GW(Q8K, "Q8K") GW(IQ4XS, "IQ4XS") GW(IQ4NL, "IQ4NL")
+        GW(Q4_0, "Q4_0") GW(Q4_1, "Q4_1") GW(Q5_0, "Q5_0") GW(Q5_1, "Q5_1") GW(Q8_0, "Q8_0") GW(Q8_1, "Q8_1")
     }
     if (argc > 3) {
         std::vector<Variant> keep;
