@@ -1259,7 +1259,13 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_wait_rec(const uint8_t *__
     const uint32_t rec = (uint32_t)table[record_slot<PX>(t)].dst;
     const uint64_t rem = nblocks - t * G::TB;
     const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
-    const uint32_t z = pf.wait ? group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
+    uint32_t zp = 0;
+    if (MODE == 2) {       // the probe's own address waits for the record (a scalar load that hits L2 or the scalar cache)
+        uint32_t zero;
+        asm volatile("s_and_b32 %0, 0, %1" : "=s"(zero) : "s"(rec));
+        zp = zero;
+    }
+    const uint32_t z = pf.wait ? group_wait(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS + zp) : 0u;
     uint32_t zr = 0;
     if (MODE == 0) {
         uint32_t zero;
@@ -1271,6 +1277,74 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_wait_rec(const uint8_t *__
     });
     deq_tile<F, O, true>(lds, src + t * G::TBYTES + z + zr, nblk, dst + t * G::ELEMS, line);
     if (MODE == 1) asm volatile("" ::"s"(rec));
+}
+
+// ---- batch kernel without a tile table: the tile's tensor is found by a scalar binary search over the descriptors ----
+// The descriptor array is a few KB and stays in the scalar cache; no per-tile record is read from memory.
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_bs(const TensorDesc *__restrict__ desc, uint32_t ntensors,
+                                                           uint64_t ntiles, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    uint32_t lo = 0, hi = ntensors - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (desc[mid].first_tile <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const TensorDesc d = desc[lo];
+    const uint64_t k = t - d.first_tile;
+    const uint64_t left = d.blocks - k * G::TB;
+    const uint32_t nblk = left < G::TB ? (uint32_t)left : G::TB;
+    const uint8_t *src = (const uint8_t *)d.src + k * G::TBYTES;
+    typename O::T *dst = (typename O::T *)d.dst + k * G::ELEMS;
+    uint32_t z = 0;
+    if (pf.wait) {
+        const uint64_t g = (t >> pf.wait) << pf.wait;            // the group's first tile, or this tensor's first
+        const uint64_t kg = g > d.first_tile ? g - d.first_tile : 0;
+        z = group_wait((const typename O::T *)d.dst + kg * G::ELEMS);
+    }
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        // the far tile is rarely more than a few tensors on: walk from this one
+        uint32_t dd = lo;
+        while (dd + 1 < ntensors && desc[dd + 1].first_tile <= tt) ++dd;
+        const uint64_t kk = tt - desc[dd].first_tile;
+        return (kk + 1) * G::TB <= desc[dd].blocks ? (const uint8_t *)desc[dd].src + kk * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + z, nblk, dst, line);
+}
+
+// ---- batch kernel with one record per 64 tiles ("run"): tensors start on run boundaries -------------------------------
+// The table is 64 times smaller (it stays in L2), a record line serves 512 consecutive workgroups, and the group
+// start needs no second lookup: a group of up to 64 tiles lies inside one run.
+struct RunRef {
+    uint64_t src;      // first block of the run
+    uint64_t dst;      // first output element of the run
+    uint64_t blocks;   // blocks from the run's start to the end of its tensor (0: padding)
+    uint64_t pad;
+};
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_run(const RunRef *__restrict__ runs, uint64_t nruns, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const RunRef r = runs[t >> 6];
+    const uint32_t k = (uint32_t)t & 63u;
+    if ((uint64_t)k * G::TB >= r.blocks) return;                  // padding behind a tensor's last tile
+    const uint64_t left = r.blocks - (uint64_t)k * G::TB;
+    const uint32_t nblk = left < G::TB ? (uint32_t)left : G::TB;
+    uint32_t z = 0;
+    if (pf.wait) z = group_wait((const typename O::T *)r.dst + (uint64_t)((k >> pf.wait) << pf.wait) * G::ELEMS);
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if ((tt >> 6) >= nruns) return nullptr;
+        const RunRef f = runs[tt >> 6];
+        const uint64_t kk = tt & 63u;
+        return (kk + 1) * G::TB <= f.blocks ? (const uint8_t *)f.src + kk * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)r.src + (uint64_t)k * G::TBYTES + z, nblk,
+                         (typename O::T *)r.dst + (uint64_t)k * G::ELEMS, line);
 }
 
 }  // namespace ggq

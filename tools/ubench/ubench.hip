@@ -244,14 +244,77 @@ void add_group_wait(std::vector<UbVariant> &vs, const char *name, uint32_t ty, u
             vs.push_back({label, bytes, [=](hipStream_t s) {
                               hipLaunchKernelGGL((deq_batch_early<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab2, ntiles, pf, tob); }, {}});
     };
+    {   // the tensor cut into 226 pieces of uneven size (whole tiles), as a model's tensor table would be
+        const uint32_t NT = 226;
+        std::vector<TensorDesc> desc;
+        uint64_t tile = 0;
+        for (uint32_t i = 0; i < NT && tile < ntiles; ++i) {
+            uint64_t want = ntiles / NT * (1 + (i * 7) % 5) / 3 + 1;
+            if (i + 1 == NT || tile + want > ntiles) want = ntiles - tile;
+            const uint64_t blk0 = tile * G::TB;
+            const uint64_t nb = std::min<uint64_t>(want * G::TB, blocks - blk0);
+            desc.push_back({(uint64_t)(uintptr_t)d_in + tile * G::TBYTES, (uint64_t)(uintptr_t)d_out + tile * tob, nb, tile});
+            tile += want;
+        }
+        if (tile < ntiles) {   // whatever is left goes to one last piece
+            const uint64_t blk0 = tile * G::TB;
+            desc.push_back({(uint64_t)(uintptr_t)d_in + tile * G::TBYTES, (uint64_t)(uintptr_t)d_out + tile * tob, blocks - blk0, tile});
+        }
+        TensorDesc *d_desc;
+        CK(hipMalloc(&d_desc, desc.size() * sizeof(TensorDesc)));
+        CK(hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(TensorDesc), hipMemcpyHostToDevice));
+        const uint32_t nd = (uint32_t)desc.size();
+        auto add_bs = [&](const char *what, Prefetch pf) {
+            char label[112];
+            std::snprintf(label, sizeof label, "gw %s batch-search %s", name, what);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_bs<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_desc, nd, ntiles, pf); }, {}});
+        };
+        add_bs("batch schedule", prefetch_for(ty, out_ty, true));
+        add_bs("single schedule", prefetch_for(ty, out_ty, false));
+        for (uint32_t w : {3u, 4u, 5u, 6u})
+            for (uint32_t l : {0u, 1280u, 2048u}) {
+                char what[48];
+                std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
+                add_bs(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
+            }
+    }
+    {   // one record per 64 tiles
+        const uint64_t nruns = (ntiles + 63) / 64;
+        std::vector<RunRef> runs(nruns);
+        for (uint64_t r = 0; r < nruns; ++r)
+            runs[r] = {(uint64_t)(uintptr_t)d_in + r * 64 * G::TBYTES, (uint64_t)(uintptr_t)d_out + r * 64 * tob, blocks - r * 64 * G::TB, 0};
+        RunRef *d_runs;
+        CK(hipMalloc(&d_runs, nruns * sizeof(RunRef)));
+        CK(hipMemcpy(d_runs, runs.data(), nruns * sizeof(RunRef), hipMemcpyHostToDevice));
+        const unsigned grid_r = (unsigned)(nruns * 64);
+        auto add_run = [&](const char *what, Prefetch pf) {
+            char label[112];
+            std::snprintf(label, sizeof label, "gw %s batch-runs %s", name, what);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              hipLaunchKernelGGL((deq_batch_run<F, O>), dim3(grid_r), dim3(WG_THREADS), 0, s, d_runs, nruns, pf); }, {}});
+        };
+        add_run("batch schedule", prefetch_for(ty, out_ty, true));
+        add_run("single schedule", prefetch_for(ty, out_ty, false));
+        for (uint32_t w : {3u, 4u, 5u, 6u})
+            for (uint32_t l : {0u, 1280u, 2048u}) {
+                char what[48];
+                std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
+                add_run(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
+            }
+    }
     for (uint32_t w : {0u, 3u, 5u})
         for (int mode = 0; mode < 2; ++mode) {
             char label[112];
             const Prefetch pf{0, 0, w};
             std::snprintf(label, sizeof label, "gw %s single+record-%s W%u off", name, mode ? "unused" : "waited", w ? 1u << w : 0u);
-            if (mode == 0)
+            if (mode == 0) {
                 vs.push_back({label, bytes, [=](hipStream_t s) {
                                   hipLaunchKernelGGL((deq_one_wait_rec<F, O, 0>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
+                std::snprintf(label, sizeof label, "gw %s single+record-before-probe W%u off", name, w ? 1u << w : 0u);
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_one_wait_rec<F, O, 2>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
+            }
             else
                 vs.push_back({label, bytes, [=](hipStream_t s) {
                                   hipLaunchKernelGGL((deq_one_wait_rec<F, O, 1>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, pf, d_tab); }, {}});
