@@ -1347,4 +1347,28 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch_run(const RunRef *__rest
                          (typename O::T *)r.dst + (uint64_t)k * G::ELEMS, line);
 }
 
+// ---- burst prefetch (HBM -> memory-side cache, far ahead) plus a near touch (memory-side cache -> this XCD's L2) --------
+// Every workgroup also touches the lines of the tile `near` tiles ahead (a multiple of 8: the same XCD in round-robin
+// dispatch), so that the workgroup which decodes it finds its input in L2 instead of the memory-side cache.
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_near(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                           uint64_t nblocks, Prefetch pf, uint32_t near) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    uint32_t touch2 = 0;
+    if (near && threadIdx.x < G::LINES && (t + near + 1) * G::TB <= nblocks) {
+        const uint8_t *base = src + (t + near) * G::TBYTES;
+        const uint8_t *ln = (const uint8_t *)((uintptr_t)base & ~(uintptr_t)127) + 128u * threadIdx.x;
+        if (ln < base + G::TBYTES) touch2 = *(const uint32_t *)ln;
+    }
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES, nblk, dst + t * G::ELEMS, line);
+    asm volatile("" ::"v"(touch2));
+}
+
 }  // namespace ggq

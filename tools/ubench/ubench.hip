@@ -1363,6 +1363,27 @@ int main(int argc, char **argv) {
 #define SWTS(F, O, NAME) SWT(F, O, 512, 2, NAME) SWT(F, O, 512, 4, NAME) SWT(F, O, 256, 4, NAME) SWT(F, O, 256, 8, NAME) SWT(F, O, 512, 3, NAME)
         SWTS(Q6K, OutF16, "Q6K f16") SWTS(Q8_0, OutF32, "Q8_0 f32") SWTS(Q4K, OutF16, "Q4K f16") SWTS(Q4K, OutF32, "Q4K f32")
     }
+    // ---- burst prefetch plus a near touch into the own L2
+    {
+#define NEAR(F, O, OT, NAME)                                                                                   \
+        {                                                                                                      \
+            const uint64_t blocks = elems / F::N;                                                              \
+            const unsigned grid = (unsigned)((blocks + TileGeom<F, O>::TB - 1) / TileGeom<F, O>::TB);          \
+            const double bytes = (double)elems * ((double)F::BYTES / F::N + sizeof(typename O::T));            \
+            const Prefetch ship = prefetch_for(F##_ID, OT, false);                                             \
+            for (uint32_t near : {0u, 8u, 16u, 32u, 64u, 128u, 256u, 512u, 12u, 100u}) {                       \
+                char label[96];                                                                                \
+                std::snprintf(label, sizeof label, "near %s +%u", NAME, near);                                 \
+                vs.push_back({label, bytes, [=](hipStream_t s) {                                               \
+                                  hipLaunchKernelGGL((deq_one_near<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, \
+                                                     (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ship, near); }, {}}); \
+            }                                                                                                  \
+            vs.push_back({"near " NAME " shipped", bytes, [=](hipStream_t s) {                                 \
+                              hipLaunchKernelGGL((deq_one<F, O, true>), dim3(grid), dim3(WG_THREADS), 0, s,    \
+                                                 (const uint8_t *)d_in, (typename O::T *)d_out, blocks, ship); }, {}}); \
+        }
+        NEAR(Q4K, OutF32, 0u, "Q4K f32") NEAR(Q6K, OutF32, 0u, "Q6K f32") NEAR(Q2K, OutF16, 1u, "Q2K f16")
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
