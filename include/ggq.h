@@ -91,8 +91,10 @@ ggq_status ggq_dequantize_slice(uint32_t ggml_type, uint32_t out_type,
  * device pointers on the current device, and the kernel is enqueued on
  * `hip_stream` (a hipStream_t, NULL = default stream) without synchronizing.
  * d_dst must be 16-byte aligned (GGQ_MISALIGNED otherwise); d_src may have any
- * alignment.  No counterpart in the reference (it has no device memory); this
- * is the form the hot path is benchmarked through. */
+ * alignment.  d_dst must be readable as well as writable: some kernels load a
+ * word of the destination before they overwrite it (only for its timing; what
+ * d_dst held before never reaches the result).  No counterpart in the reference
+ * (it has no device memory); this is the form the hot path is benchmarked through. */
 ggq_status ggq_dequantize_device(uint32_t ggml_type, uint32_t out_type,
                                  void *d_dst, size_t dst_elems,
                                  const void *d_src, size_t src_blocks,
