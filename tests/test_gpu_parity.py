@@ -381,3 +381,27 @@ def test_batch_plan_replayed_from_a_graph(torch_cuda, oracle):
             got = d.view(t.int16).cpu().numpy().view(np.uint16)
             assert same_bits16(got, want, "f16"), (rep, ty, first_diff(got, want))
     plan.close()
+
+
+@pytest.mark.parametrize("ty,out", [(8, "f32"), (14, "f16"), (12, "f16"), (13, "bf16"), (9, "f32"), (12, "f32")])
+def test_result_does_not_depend_on_what_the_destination_held(torch_cuda, oracle, ty, out):
+    """Some kernels load a word of the destination before they overwrite it (the group start).  Whatever the
+    destination held -- zeros, all ones, NaN patterns -- the result is the oracle's."""
+    import gguf_amd as g
+    from gguf_amd import synth
+    t = torch_cuda
+    blocks = 70_000 if g.block_elems(ty) == 32 else 9_000          # a few hundred tiles: many groups
+    packed = synth.random_blocks(ty, blocks, 4242 + ty)
+    src = t.from_numpy(packed).cuda()
+    dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
+    o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
+    want = oracle.dequantize(ty, packed, o_out, threads=4)
+    for fill in (0x00, 0xFF, 0x7F):
+        dst = t.empty(blocks * g.block_elems(ty), dtype=dt, device="cuda")
+        dst.view(t.uint8).fill_(fill)
+        g.dequantize_slice(ty, dst, src)
+        t.cuda.synchronize()
+        if out == "f32":
+            assert same_bits(dst.cpu().numpy(), want), (ty, out, fill)
+        else:
+            assert same_bits16(dst.view(t.int16).cpu().numpy().view(np.uint16), want, out), (ty, out, fill)
