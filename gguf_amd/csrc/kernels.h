@@ -145,6 +145,9 @@ struct Prefetch {
 // This is the alternative to the burst prefetch for streams with a larger share of reads: with the packed input
 // at 21 % of the traffic and more (every 2-byte output except Q2_K and Q3_K; the 8-bit formats with 4-byte
 // output) it beats the burst by 2-7 %, below that it loses by 4-17 % (measurements at schedule.h).
+// The address is wave-uniform, so the compiler issues the load through the scalar cache, and that is part of the
+// effect: the same probe forced onto the vector path (measured) turns the gain into a loss of 10-18 points.  The
+// description above is therefore a model that fits the measurements, not an established mechanism.
 __device__ __forceinline__ uint32_t group_wait(const void *group_dst) {
     const uint32_t seen = *(const uint32_t *)group_dst;
     uint32_t zero;

@@ -1371,4 +1371,79 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_near(const uint8_t *__rest
     asm volatile("" ::"v"(touch2));
 }
 
+// ---- record and probe through the VECTOR memory path instead of the scalar cache ---------------------------------------
+// The compiler turns loads from wave-uniform addresses into scalar loads; the scalar cache has a narrow miss path that
+// two or three CUs share.  A zero the compiler cannot see through makes the address look divergent.
+__device__ __forceinline__ uint32_t opaque_lane_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+__device__ __forceinline__ uint32_t group_wait_v(const void *group_dst) {
+    const uint32_t seen = *(const uint32_t *)((const uint8_t *)group_dst + opaque_lane_zero());
+    uint32_t zero;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(seen));
+    return __builtin_amdgcn_readfirstlane(zero);
+}
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    // the builtin returns int: without the casts the low half would be sign-extended over the high half
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+// MODE bit 0: record by vector load; bit 1: probe by vector load (if pf.wait)
+template <class F, class O, int MODE>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_v(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    TileRef me;
+    if (MODE & 1) {
+        const TileRef *p = table + record_slot<PX>(t) + opaque_lane_zero();
+        const uint4v raw = *(const uint4v *)p;
+        me.src_nblk = rfl64(((uint64_t)raw.y << 32) | raw.x);
+        me.dst = rfl64(((uint64_t)raw.w << 32) | raw.z);
+    } else {
+        me = table[record_slot<PX>(t)];
+    }
+    uint32_t z = 0;
+    if (pf.wait) {
+        const uint64_t g = (t >> pf.wait) << pf.wait;
+        uint64_t gd;
+        if (MODE & 1) {
+            const TileRef *p = table + record_slot<PX>(g) + opaque_lane_zero();
+            const uint2v raw = *(const uint2v *)&p->dst;
+            gd = rfl64(((uint64_t)raw.y << 32) | raw.x);
+        } else {
+            gd = table[record_slot<PX>(g)].dst;
+        }
+        z = (MODE & 2) ? group_wait_v((const void *)gd) : group_wait((const void *)gd);
+    }
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull) + z, (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)me.dst, line);
+}
+
+// the single-tensor kernel with the probe through the vector path
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_one_vprobe(const uint8_t *__restrict__ src, typename O::T *__restrict__ dst,
+                                                             uint64_t nblocks, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t z = pf.wait ? group_wait_v(dst + ((t >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + t * G::TBYTES + z, nblk, dst + t * G::ELEMS, line);
+}
+
 }  // namespace ggq

@@ -279,6 +279,37 @@ void add_group_wait(std::vector<UbVariant> &vs, const char *name, uint32_t ty, u
                 add_bs(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
             }
     }
+    {   // record and probe through the vector memory path
+        auto add_v = [&](const char *what, Prefetch pf, int mode) {
+            char label[112];
+            std::snprintf(label, sizeof label, "gw %s batch-vec%d %s", name, mode, what);
+            if (mode == 1)
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_batch_v<F, O, 1>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf); }, {}});
+            else if (mode == 3)
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_batch_v<F, O, 3>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf); }, {}});
+            else
+                vs.push_back({label, bytes, [=](hipStream_t s) {
+                                  hipLaunchKernelGGL((deq_batch_v<F, O, 2>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf); }, {}});
+        };
+        add_v("batch schedule", prefetch_for(ty, out_ty, true), 1);
+        add_v("single schedule", prefetch_for(ty, out_ty, false), 1);
+        add_v("single schedule", prefetch_for(ty, out_ty, false), 3);
+        add_v("single schedule", prefetch_for(ty, out_ty, false), 2);
+        for (uint32_t w : {3u, 5u})
+            for (uint32_t l : {0u, 1280u}) {
+                char what[48];
+                std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
+                add_v(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w}, 3);
+                add_v(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w}, 1);
+            }
+        char label[112];
+        std::snprintf(label, sizeof label, "gw %s single-vprobe single schedule", name);
+        const Prefetch ps = prefetch_for(ty, out_ty, false);
+        vs.push_back({label, bytes, [=](hipStream_t s) {
+                          hipLaunchKernelGGL((deq_one_vprobe<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_in, (typename O::T *)d_out, blocks, ps); }, {}});
+    }
     {   // one record per 64 tiles
         const uint64_t nruns = (ntiles + 63) / 64;
         std::vector<RunRef> runs(nruns);
