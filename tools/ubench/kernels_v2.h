@@ -1446,4 +1446,26 @@ __global__ __launch_bounds__(WG_THREADS) void deq_one_vprobe(const uint8_t *__re
     deq_tile<F, O, true>(lds, src + t * G::TBYTES + z, nblk, dst + t * G::ELEMS, line);
 }
 
+// ---- group start on a plain copy (what the LDS-free streaming kernels would gain) --------------------------------------
+// Workgroup b copies pieces [b * 256 * S, (b + 1) * 256 * S); the group's probe is the first dword of the group's output.
+template <int S>
+__global__ __launch_bounds__(STREAM_THREADS) void copy16_group(uint4v *__restrict__ dst, const uint4v *__restrict__ src,
+                                                               uint64_t total, uint32_t wait) {
+    const uint64_t b = blockIdx.x;
+    uint32_t z = 0;
+    if (wait) z = group_wait(dst + ((b >> wait) << wait) * (STREAM_THREADS * S));
+    const uint4v *s2 = src + z;
+    uint4v v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const uint64_t p = (b * S + k) * STREAM_THREADS + threadIdx.x;
+        if (p < total) v[k] = __builtin_nontemporal_load(s2 + p);
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const uint64_t p = (b * S + k) * STREAM_THREADS + threadIdx.x;
+        if (p < total) __builtin_nontemporal_store(v[k], dst + p);
+    }
+}
+
 }  // namespace ggq

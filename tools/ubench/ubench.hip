@@ -1415,6 +1415,20 @@ int main(int argc, char **argv) {
         }
         NEAR(Q4K, OutF32, 0u, "Q4K f32") NEAR(Q6K, OutF32, 0u, "Q6K f32") NEAR(Q2K, OutF16, 1u, "Q2K f16")
     }
+    // ---- group start on a plain copy
+    {
+        const uint64_t total = elems * 2 / 16;          // 2 GiB copied: 2 B per element of `elems`
+#define CPG(S)                                                                                                  \
+        for (uint32_t w : {0u, 2u, 3u, 4u, 5u, 6u, 8u}) {                                                       \
+            char label[96];                                                                                     \
+            std::snprintf(label, sizeof label, "cpg copy 256 x %d, group %u", S, w ? 1u << w : 0u);             \
+            const unsigned grid = (unsigned)((total + 256 * S - 1) / (256 * S));                                \
+            vs.push_back({label, 2.0 * 16 * total, [=](hipStream_t s) {                                         \
+                              hipLaunchKernelGGL((copy16_group<S>), dim3(grid), dim3(STREAM_THREADS), 0, s,     \
+                                                 (uint4v *)d_out, (const uint4v *)d_in, total, w); }, {}});     \
+        }
+        CPG(1) CPG(2) CPG(4)
+    }
     // ---- occupancy probes: dynamic LDS that the kernel never touches limits the workgroups per CU
     // (160 KiB of LDS per CU), i.e. the bytes of stores a CU has in flight
     {
