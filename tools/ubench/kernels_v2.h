@@ -1468,4 +1468,30 @@ __global__ __launch_bounds__(STREAM_THREADS) void copy16_group(uint4v *__restric
     }
 }
 
+// ---- batch kernel whose probe address needs no record: outputs lie in one arena, in tile order -------------------------
+// probe = arena + group's first tile * tile_out_bytes + skew, clamped into the arena.  skew models the error that
+// short last tiles of earlier tensors would cause in a real plan.
+template <class F, class O>
+__global__ __launch_bounds__(WG_THREADS) void deq_batch_arena(const TileRef *__restrict__ table, uint64_t ntiles, Prefetch pf,
+                                                              const uint8_t *__restrict__ arena, uint64_t arena_bytes, uint64_t skew) {
+    typedef TileGeom<F, O> G;
+    constexpr bool PX = RecordOrder<O>::PER_XCD;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint64_t t = blockIdx.x;
+    uint32_t z = 0;
+    if (pf.wait) {
+        uint64_t off = ((t >> pf.wait) << pf.wait) * (uint64_t)(G::ELEMS * sizeof(typename O::T)) + skew;
+        if (off + 128 > arena_bytes) off = arena_bytes - 128;
+        z = group_wait(arena + off);
+    }
+    const TileRef me = table[record_slot<PX>(t)];
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(t, pf, [&](uint64_t tt) -> const uint8_t * {
+        if (tt >= ntiles) return nullptr;
+        const uint64_t far = table[record_slot<PX>(tt)].src_nblk;
+        return (far >> 48) == G::TB ? (const uint8_t *)(far & 0xFFFFFFFFFFFFull) : nullptr;
+    });
+    deq_tile<F, O, true>(lds, (const uint8_t *)(me.src_nblk & 0xFFFFFFFFFFFFull) + z, (uint32_t)(me.src_nblk >> 48),
+                         (typename O::T *)me.dst, line);
+}
+
 }  // namespace ggq

@@ -279,6 +279,20 @@ void add_group_wait(std::vector<UbVariant> &vs, const char *name, uint32_t ty, u
                 add_bs(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
             }
     }
+    {   // probe address by arithmetic over an output arena
+        const uint64_t arena_bytes = ntiles * (uint64_t)tob;
+        for (uint64_t skew : {0ull, 4ull << 20})
+            for (uint32_t w : {3u, 4u, 5u, 6u})
+                for (uint32_t l : {0u, 1280u}) {
+                    char label[112];
+                    std::snprintf(label, sizeof label, "gw %s batch-arena W%u %s%u skew %lluM", name, 1u << w, l ? "P1 L" : "off ", l,
+                                  (unsigned long long)(skew >> 20));
+                    const Prefetch pf = l ? Prefetch{1, l, w} : Prefetch{0, 0, w};
+                    vs.push_back({label, bytes, [=](hipStream_t s) {
+                                      hipLaunchKernelGGL((deq_batch_arena<F, O>), dim3(grid), dim3(WG_THREADS), 0, s, d_tab, ntiles, pf,
+                                                         (const uint8_t *)d_out, arena_bytes, skew); }, {}});
+                }
+    }
     {   // record and probe through the vector memory path
         auto add_v = [&](const char *what, Prefetch pf, int mode) {
             char label[112];
