@@ -1494,4 +1494,35 @@ __global__ __launch_bounds__(WG_THREADS) void deq_batch_arena(const TileRef *__r
                          (typename O::T *)me.dst, line);
 }
 
+// ---- several tensors per launch, their descriptors in the kernel arguments (no table in memory) -----------------------
+// A launch covers up to K tensors; the workgroup finds its tensor by comparing its index with the K first-tile
+// numbers (all in the kernel-argument segment, which every workgroup reads and the scalar cache keeps), then works
+// exactly like the single-tensor kernel, group start included.
+template <int K>
+struct DescPack {
+    uint32_t first[K];      // first tile of tensor j in this launch, ascending; unused entries 0xFFFFFFFF
+    uint64_t src[K], dst[K], blocks[K];
+};
+template <class F, class O, int K>
+__global__ __launch_bounds__(WG_THREADS) void deq_multi(const DescPack<K> pack, Prefetch pf) {
+    typedef TileGeom<F, O> G;
+    __shared__ uint4v lds[G::LDS_SLOTS];
+    const uint32_t t = blockIdx.x;
+    uint32_t i = 0;
+#pragma unroll
+    for (int j = 1; j < K; ++j) i += t >= pack.first[j] ? 1u : 0u;
+    const uint64_t k = t - pack.first[i];
+    const uint64_t nblocks = pack.blocks[i];
+    const uint8_t *src = (const uint8_t *)pack.src[i];
+    typename O::T *dst = (typename O::T *)pack.dst[i];
+    const uint64_t rem = nblocks - k * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    const uint32_t z = pf.wait ? group_wait(dst + ((k >> pf.wait) << pf.wait) * G::ELEMS) : 0u;
+    // the burst stays inside the tensor (a tensor's last period goes without, as in the single-tensor kernel)
+    const uint8_t *line = prefetch_line<G, sizeof(typename O::T) == 2>(k, pf, [&](uint64_t tt) -> const uint8_t * {
+        return (tt + 1) * G::TB <= nblocks ? src + tt * G::TBYTES : nullptr;
+    });
+    deq_tile<F, O, true>(lds, src + k * G::TBYTES + z, nblk, dst + k * G::ELEMS, line);
+}
+
 }  // namespace ggq

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -278,6 +279,50 @@ void add_group_wait(std::vector<UbVariant> &vs, const char *name, uint32_t ty, u
                 std::snprintf(what, sizeof what, "W%u %s%u", 1u << w, l ? "P1 L" : "off ", l);
                 add_bs(what, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
             }
+    }
+    {   // the tensor cut into 226 uneven pieces, K per launch, descriptors in the kernel arguments
+        constexpr int K = 32;
+        const uint32_t NT = 226;
+        struct Piece { uint64_t tile0, tiles, blocks; };
+        std::vector<Piece> pieces;
+        uint64_t tile = 0;
+        for (uint32_t i = 0; i < NT && tile < ntiles; ++i) {
+            uint64_t want = ntiles / NT * (1 + (i * 7) % 5) / 3 + 1;
+            if (i + 1 == NT || tile + want > ntiles) want = ntiles - tile;
+            pieces.push_back({tile, want, std::min<uint64_t>(want * G::TB, blocks - tile * G::TB)});
+            tile += want;
+        }
+        if (tile < ntiles) pieces.push_back({tile, ntiles - tile, blocks - tile * G::TB});
+        struct Launch { DescPack<K> pack; unsigned grid; };
+        auto launches = std::make_shared<std::vector<Launch>>();
+        for (size_t p0 = 0; p0 < pieces.size(); p0 += K) {
+            Launch L;
+            uint64_t acc = 0;
+            for (int j = 0; j < K; ++j) {
+                if (p0 + j < pieces.size()) {
+                    const Piece &pc = pieces[p0 + j];
+                    L.pack.first[j] = (uint32_t)acc;
+                    L.pack.src[j] = (uint64_t)(uintptr_t)d_in + pc.tile0 * G::TBYTES;
+                    L.pack.dst[j] = (uint64_t)(uintptr_t)d_out + pc.tile0 * tob;
+                    L.pack.blocks[j] = pc.blocks;
+                    acc += pc.tiles;
+                } else {
+                    L.pack.first[j] = 0xFFFFFFFFu;
+                    L.pack.src[j] = L.pack.dst[j] = L.pack.blocks[j] = 0;
+                }
+            }
+            L.grid = (unsigned)acc;
+            launches->push_back(L);
+        }
+        auto add_multi = [&](const char *what, Prefetch pf) {
+            char label[112];
+            std::snprintf(label, sizeof label, "gw %s multi%d %s", name, K, what);
+            vs.push_back({label, bytes, [=](hipStream_t s) {
+                              for (const auto &L : *launches)
+                                  hipLaunchKernelGGL((deq_multi<F, O, K>), dim3(L.grid), dim3(WG_THREADS), 0, s, L.pack, pf); }, {}});
+        };
+        add_multi("single schedule", prefetch_for(ty, out_ty, false));
+        add_multi("batch schedule", prefetch_for(ty, out_ty, true));
     }
     {   // probe address by arithmetic over an output arena
         const uint64_t arena_bytes = ntiles * (uint64_t)tob;
