@@ -44,7 +44,7 @@ thread_local std::string g_err;
 
 // Measurement knobs, read once: GGQ_NO_PREFETCH=1 switches the burst prefetch and the group start off,
 // GGQ_PREFETCH="period,lead[,wait]" replaces the schedule of every kernel.
-Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
+Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch, uint64_t elems = ~0ull) {
     static const int mode = [] {
         const char *e = std::getenv("GGQ_NO_PREFETCH");
         if (e && *e && *e != '0') return 1;
@@ -58,7 +58,7 @@ Prefetch pick_prefetch(uint32_t ty, uint32_t out_ty, bool batch) {
     }();
     if (mode == 1) return Prefetch{0, 0};
     if (mode == 2) return forced;
-    return prefetch_for(ty, out_ty, batch);
+    return prefetch_for(ty, out_ty, batch, elems);
 }
 
 bool hip_ok(hipError_t e, const char *what) {
@@ -183,7 +183,7 @@ ggq_status launch_blocks(uint32_t ty, void *d_dst, const void *d_src, uint64_t b
             hipLaunchKernelGGL((deq_one<F, O, kNT>), dim3((uint32_t)n), dim3(WG_THREADS), 0, st, \
                                (const uint8_t *)d_src + t0 * G::TBYTES,                       \
                                (typename O::T *)d_dst + t0 * G::ELEMS, blocks - t0 * G::TB,   \
-                               pick_prefetch(ID, out_id<O>(), false));                        \
+                               pick_prefetch(ID, out_id<O>(), false, blocks * F::N));         \
         }                                                                                     \
         break;                                                                                \
     }

@@ -14,7 +14,7 @@ namespace ggq {
 // 2-20 % for the 2- to 5-bit formats and costs 3-7 % for the 8-bit ones, where it stays off.
 // period 1 = every workgroup touches its own tile `lead` ahead (no burst).
 // A third field k > 0 switches the group start on (groups of 2^k workgroups).
-inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
+inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch, uint64_t elems = ~0ull) {
     const bool wide = out_ty == GGQ_TYPE_F32;
     if (batch) {
         if (!wide) {
@@ -47,10 +47,20 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
     // 80.8, Q4_0 83.4 / 83.6 against 80.6 / 80.9, Q4_1 84.3 against 79.3, Q5_0 85.1 against 78.3, Q5_1 85.3 against
     // 79.0, Q8_0 83.6 against 77.2, Q8_1 83.9 against 76.6.  With a smaller share of reads the burst wins by 4-17 %.
     // The batch kernel does not take it: with the table's record loads in the stream the same wait LOSES 3-18 %.
+    // Those figures are long runs over 1 Gi elements.  A tensor decoded once, its input cold
+    // (tools/probe_cold.py), gains +2...+11 % at 512 Mi elements, +-3 % at
+    // 128 Mi, and below that no schedule at all is as good or better (the old bursts lose up to 5 % there): tensors
+    // under 64 Mi elements run these kernels without burst and without group start, except that the 8-bit formats
+    // with 4-byte output keep their burst.
+    const bool large = elems >= (64ull << 20);
     if (!wide) {
         switch (ty) {
         case GGQ_TYPE_Q2K: return {640, 1280};
         case GGQ_TYPE_Q3K: return {1024, 1024};
+        default: break;
+        }
+        if (!large) return {0, 0};
+        switch (ty) {
         case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: case GGQ_TYPE_IQ4NL: case GGQ_TYPE_Q4_0: return {1, 2048, 6};
         case GGQ_TYPE_Q5K: return {1, 1280, 6};
         case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: return {1, 1280, 5};
@@ -64,7 +74,7 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch) {
     case GGQ_TYPE_Q5K: return {640, 1280};
     case GGQ_TYPE_Q6K: return {1024, 1024};
     case GGQ_TYPE_Q4_1: return {512, 1280};
-    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: case GGQ_TYPE_Q8K: return {0, 0, 5};
+    case GGQ_TYPE_Q8_0: case GGQ_TYPE_Q8_1: case GGQ_TYPE_Q8K: return large ? Prefetch{0, 0, 5} : Prefetch{640, 1024};
     default: return {640, 1024};
     }
 }

@@ -1,7 +1,7 @@
 """Probe: single-tensor decode of a COLD input (caches evicted by READING 2 GiB before every launch; a
 fill would leave dirty lines whose write-back lands inside the timed launch), with
 the burst prefetch on and off (GGQ_NO_PREFETCH=1 in a second process), for tensor sizes from 4 Mi to 512 Mi
-elements.  Repeated launches over the same small input would find it in the memory-side cache and
+elements (PROBE_TYPES, PROBE_OUT, PROBE_SIZES select others).  Repeated launches over the same small input would find it in the memory-side cache and
 say nothing about a tensor that is decoded once.
 Run on the GPU box: python tools/probe_cold.py ; GGQ_NO_PREFETCH=1 python tools/probe_cold.py
 """
@@ -21,11 +21,13 @@ def main():
     evict = torch.zeros(2 << 28, dtype=torch.int32, device=dev)    # 2 GiB
     tag = "prefetch off" if os.environ.get("GGQ_NO_PREFETCH") else "prefetch " + os.environ.get("GGQ_PREFETCH", "on ")
     sizes = [int(x) for x in os.environ.get("PROBE_SIZES", "4,16,45,128,512").split(",")]
-    for ty in (GGmlType.Q4K, GGmlType.Q6K):
+    types = [GGmlType[x] for x in os.environ.get("PROBE_TYPES", "Q4K,Q6K").split(",")]
+    out_dt = {"f32": torch.float32, "f16": torch.float16}[os.environ.get("PROBE_OUT", "f32")]
+    for ty in types:
         for mi in sizes:
             n = mi << 20
-            src = synth.random_blocks_device(ty, n // 256, 3, dev)
-            dst = torch.empty(n, dtype=torch.float32, device=dev)
+            src = synth.random_blocks_device(ty, n // g.block_elems(ty), 3, dev)
+            dst = torch.empty(n, dtype=out_dt, device=dev)
             for _ in range(20):                      # clocks up
                 g.dequantize_slice(ty, dst, src)
             ts = []
@@ -39,7 +41,7 @@ def main():
                 ts.append(e0.elapsed_time(e1))
             ts.sort()
             med = ts[len(ts) // 2]
-            per = g.block_bytes(ty) / 256 + 4
+            per = g.block_bytes(ty) / g.block_elems(ty) + dst.element_size()
             print(f"{tag} {ty.name:4s} {mi:4d} Mi elements  {med * 1e3:9.1f} us  {n * per / med / 1e6:7.0f} GB/s", flush=True)
 
 
