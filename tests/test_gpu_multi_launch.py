@@ -11,10 +11,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("wide", ["0", "1"])
-def test_split_launch_paths(oracle, wide):
-    """wide = 1 also forces the 64-bit index kernels that tensors of 2^32 pieces and more take."""
+@pytest.mark.parametrize("wide,schedule", [("0", None), ("1", None), ("0", "1,8,2"), ("0", "4,8,3"), ("0", "0,0,1")])
+def test_split_launch_paths(oracle, wide, schedule):
+    """wide = 1 also forces the 64-bit index kernels that tensors of 2^32 pieces and more take.  `schedule`
+    (GGQ_PREFETCH = period,lead,wait) forces the group start -- which the library only uses from 64 Mi elements --
+    and short burst periods onto these small inputs, in the single-tensor and in the batch kernel."""
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_launch_child.py")
     env = dict(os.environ, GGQ_MAX_GRID="3", GGQ_WIDE_INDEX=wide)
+    if schedule:
+        env["GGQ_PREFETCH"] = schedule
     r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-2000:], r.stderr[-4000:])

@@ -390,12 +390,13 @@ def test_result_does_not_depend_on_what_the_destination_held(torch_cuda, oracle,
     import gguf_amd as g
     from gguf_amd import synth
     t = torch_cuda
-    blocks = 70_000 if g.block_elems(ty) == 32 else 9_000          # a few hundred tiles: many groups
+    # 67 Mi elements: from 64 Mi on the single-tensor kernels of these formats use the group start
+    blocks = (67 << 20) // g.block_elems(ty)
     packed = synth.random_blocks(ty, blocks, 4242 + ty)
     src = t.from_numpy(packed).cuda()
     dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[out]
     o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
-    want = oracle.dequantize(ty, packed, o_out, threads=4)
+    want = oracle.dequantize(ty, packed, o_out, threads=16)
     for fill in (0x00, 0xFF, 0x7F):
         dst = t.empty(blocks * g.block_elems(ty), dtype=dt, device="cuda")
         dst.view(t.uint8).fill_(fill)
