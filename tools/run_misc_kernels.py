@@ -1,4 +1,5 @@
-"""The kernels beside the f32 decode -- quantize, widen, narrow, the permute_qk row gather, scale -- run a few
+"""The kernels beside the batch decode -- quantize, widen, narrow, the permute_qk row gather, scale, and four
+single-tensor decodes that use the group start -- run a few
 times each on 1 Gi elements, for `rocprofv3 --kernel-trace --stats` (profiles/summarize_misc.py prices
 the averages against 8 TB/s).  Run on the GPU box."""
 import json
@@ -56,5 +57,18 @@ for ty, buf, key in ((T.F16, h.view(torch.uint8), "scale_vec<1"), (T.F32, x.view
         R.scale(ty, buf, 1.4, out=dst)
     bytes_per_launch[key] = 2 * buf.numel()
     del dst
+torch.cuda.synchronize()
+
+# single-tensor decode kernels whose schedule is the group start: 1 Gi elements each
+from gguf_amd import synth  # noqa: E402
+del x, h
+for ty, out_dt, key in ((T.Q8_0, torch.float32, "deq_one<ggq::Q8_0, ggq::OutF32"), (T.Q6K, torch.float16, "deq_one<ggq::Q6K, ggq::OutF16"),
+                        (T.Q4K, torch.float16, "deq_one<ggq::Q4K, ggq::OutF16"), (T.Q5_1, torch.float16, "deq_one<ggq::Q5_1, ggq::OutF16")):
+    src = synth.random_blocks_device(ty, n // g.block_elems(ty), 5, "cuda")
+    dst = torch.empty(n, dtype=out_dt, device="cuda")
+    for _ in range(reps):
+        g.dequantize_slice(ty, dst, src)
+    bytes_per_launch[key] = src.numel() + n * dst.element_size()
+    del src, dst
 torch.cuda.synchronize()
 print(json.dumps(bytes_per_launch))
