@@ -9,11 +9,17 @@ One "step" decodes one whole synthetic tensor set that is already resident in HB
 per block type present).  Default workload: the Llama-7B-shaped tensor set under
 the Q4_K_M type mixture (6.74 G elements, 226 tensors, Q4_K + Q6_K).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): by default ONE such set is
-dealt to the ranks by the index partition of gguf_amd.shard (strong scaling: the way a
-whole-model conversion shards its tensors); `--scaling weak` gives every rank a whole set.
-No collective takes part in the data path; the process group (gloo, host tensors) carries
-only the barriers around the timed regions and the max-over-ranks of the times.
+N > 1, one rank (process) per GPU.  Either an external launcher starts the ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`: RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or plain `python bench.py --gpus N`
+starts them itself: with WORLD_SIZE unset the parent -- which never touches the GPU -- spawns N
+fresh children with those variables set, relays rank 0's JSON line and exits with the ranks' code
+(one process fanning out over workers, like the reference's writer threads,
+xtask/src/utils/write.rs:64-99).  By default ONE tensor set is dealt to the ranks by the index
+partition of gguf_amd.shard (strong scaling: the way a whole-model conversion shards its
+tensors); `--scaling weak` gives every rank a whole set.  No collective takes part in the data
+path; the process group (gloo, host tensors) carries only the barriers around the timed regions
+and the max-over-ranks of the times.
 
 Prints ONE JSON line on rank 0.  `value` = decoded (output) bytes of the whole job
 per second, inputs resident in HBM.  `roofline` prices the dominant kernel (the Q4_K
@@ -365,8 +371,61 @@ def streamed_leg(share, local, steps, fence, max_over_ranks):
     return elapsed, staging
 
 
+def self_launch(n):
+    """Plain `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child
+    processes (same command line; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait for them, pass rank 0's
+    standard output (the one JSON line) through, and return the exit code: rank 0's, or the first non-zero one.
+    This process imports neither torch nor the library and makes no HIP call, so every child initialises the GPU
+    in a process of its own.  A rank that fails takes the others down after a grace period, so that nobody waits
+    in a barrier for it until gloo's timeout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GGQ_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    codes = [None] * n
+    failed_at = None
+    out0 = None
+    try:
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None and p.poll() is not None:
+                    codes[r] = p.returncode
+                    if r == 0:
+                        out0 = p.stdout.read()
+                    if p.returncode != 0 and failed_at is None:
+                        failed_at = time.perf_counter()
+            if failed_at is not None and time.perf_counter() - failed_at > 20.0:
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()
+                failed_at = time.perf_counter() + 1e9          # once
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return codes[0] if codes[0] else bad[0][1]
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    affinity0 = os.sched_getaffinity(0)
     import torch
     import torch.distributed as dist
     import gguf_amd as g  # noqa: F401
@@ -377,11 +436,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world} set by the launcher (plain `python bench.py "
+                 f"--gpus N` without WORLD_SIZE starts its own ranks; under torch.distributed.run pass "
+                 f"--nproc-per-node N and --gpus N)")
+    if not torch.cuda.is_available():
+        sys.exit(f"rank {rank}: bench.py needs a GPU (there is no CPU fallback)")
     ndev = torch.cuda.device_count()
     # Normal case: one rank per GPU.  Rehearsal case (fewer GPUs than ranks, e.g. two ranks on a
     # one-GPU box): ranks share devices.  Either way the process group is gloo on host tensors: it
@@ -415,6 +474,14 @@ def main():
         t = torch.tensor([blocks, 0 if ok else 1], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t[0]), int(t[1]) == 0
+
+    # how many ranks actually took part, and on how many distinct GPUs (counted, not assumed)
+    ranks_seen, gpus_seen = 1, 1
+    if world > 1:
+        ids = [None] * world
+        p = torch.cuda.get_device_properties(local)
+        dist.all_gather_object(ids, (rank, f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"))
+        ranks_seen, gpus_seen = len({i[0] for i in ids}), len({i[1] for i in ids})
 
     # ---- the job, dealt to ranks by the index partition -----------------------------
     base, items, label = job_items(args.workload, args.scaling, world)
@@ -474,7 +541,8 @@ def main():
             if shared:      # rehearsal: ranks share a GPU, which RCCL refuses; host copies over gloo carry the logic
                 arena, group, how = share.arena.cpu(), None, "gloo on host copies (REHEARSAL)"
             else:
-                arena, group, how = share.arena, dist.new_group(backend="nccl"), "RCCL all_gather_into_tensor over xGMI"
+                arena, group = share.arena, dist.new_group(backend="nccl")
+                how = f"RCCL all_gather_into_tensor over xGMI, communicator of {dist.get_world_size(group)} ranks"
             full = shard.gather_arenas(arena, world, group)          # warm-up: communicator set-up
             fence()
             t0 = time.perf_counter()
@@ -535,19 +603,29 @@ def main():
         achieved = dom_bytes / (kern_ms[0] * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tr_path):
+        if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 key = f"{args.workload}:{args.out}:{GGmlType(dom_ty).name}"
-                if key in tr:
+                if key in tr and world == 1:
                     traffic = tr[key].get("hbm_bytes_per_launch")
                     traffic_source = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch recorded in "
                                       f"profiles/traffic.json ({tr[key].get('round', 'r01')}), not measured in this run")
+                elif key in tr:
+                    # a rank's launch covers 1/N of the set: the counters were read on the whole-set launch, so only
+                    # their ratio to that launch's algorithmic bytes carries over, not the byte count
+                    whole = sum(ne for _, ty, ne in base if int(ty) == int(dom_ty)) * per_elem
+                    ratio = tr[key]["hbm_bytes_per_launch"] / whole
+                    traffic_source = (f"none for this launch size; the one-GPU launch of the same kernel moved {ratio:.3f} x "
+                                      f"its algorithmic bytes (profiles/traffic.json, {tr[key].get('round', 'r01')})")
             except Exception:
                 traffic = None
         rec = {
             "metric": "dequantized_GBps", "value": round(pout / per / 1e9, 2), "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
+            "n_gpus": world, "ranks_seen": ranks_seen, "gpus_seen": gpus_seen,
+            "launcher": "self (bench.py started the ranks)" if os.environ.get("GGQ_BENCH_SELF_LAUNCHED") else
+                        ("external" if world > 1 else "none"),
+            "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
             "ms_per_step": round(per * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "io": "u8->" + args.out, "data": "synthetic",
@@ -581,11 +659,16 @@ def main():
                 rc = 1
         if weak is not None:
             rec["secondary"] = weak
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             if share is not None:
                 share.close()
                 share = None
             torch.cuda.empty_cache()
+            # rank 0 alone, after every GPU leg, on all the CPUs this process started with (the other ranks wait in
+            # the barrier below; bind_near_gpu had narrowed the affinity for the streamed leg)
+            os.sched_setaffinity(0, affinity0)
+            if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+                os.environ.pop("OMP_NUM_THREADS")       # torch.distributed.run's per-rank default, not a core count
             rec["cpu_baseline"] = cpu_baseline(base, args.out, args.cpu_seconds)
         print(json.dumps(rec), flush=True)
     if world > 1:
