@@ -1,0 +1,167 @@
+"""Checks on the device code hipcc generates for libggq (gfx950 ISA text and the compiler's resource remarks).
+
+The library's bit-exactness and part of its speed rest on properties of the generated code that no source-level
+test sees:
+  * no packed-f32 arithmetic (v_pk_add/mul/fma_f32) and no mixed-precision fused multiply-add (v_fma_mix*): the
+    first has given wrong results on these machines, the second turns a -0.0 product into +0.0 and fuses a
+    multiply with an add that the reference (ggml-quants/src/structs/q4_1.rs:49-60 and every other decoder)
+    rounds separately;
+  * fused multiply-adds only inside the compiler's correctly rounded division sequence (v_div_scale ...
+    v_div_fixup) of the quantizers, where the reference divides too (ggml-quants/src/structs/q4_0.rs:31);
+  * the group start of the single-tensor decode kernels: a scalar one-dword load of the destination that is
+    issued, waited for and folded into the source address before the first tile load;
+  * no scratch memory, 8 waves per SIMD and exactly the LDS bytes of the tile geometry for every decode kernel.
+This module is the parser and the checks; tests/test_codegen.py runs them on the shipped flags and on two
+sabotaged flag sets.  CPU only: hipcc cross-compiles.
+"""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gguf_amd", "csrc")
+
+
+def compile_device(out_s, flags_override=None, timeout=600):
+    """`make asm` of gguf_amd/csrc into out_s with the compiler's kernel-resource-usage remarks; returns the remarks
+    text.  flags_override replaces the Makefile's FLAGS (to show that the checks notice a missing flag)."""
+    cmd = ["make", "-s", "-C", CSRC, "asm", f"ASM_OUT={out_s}", "EXTRA=-Rpass-analysis=kernel-resource-usage"]
+    if flags_override is not None:
+        cmd.append(f"FLAGS={flags_override}")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"make asm failed:\n{r.stderr[-2000:]}")
+    return r.stderr
+
+
+def makefile_flags():
+    """The FLAGS the Makefile builds with, as one string (make -p expands them)."""
+    r = subprocess.run(["make", "-C", CSRC, "-pn", "asm"], capture_output=True, text=True, timeout=60)
+    for line in r.stdout.splitlines():
+        if line.startswith("FLAGS := ") or line.startswith("FLAGS = "):
+            return line.split("=", 1)[1].strip()
+    raise RuntimeError("FLAGS not found in make -p output")
+
+
+def functions(asm_text):
+    """{mangled name: [instruction lines]} for every function of the assembly text."""
+    out, name, body = {}, None, []
+    for line in asm_text.splitlines():
+        m = re.match(r"^(_Z[\w$.]+):", line)
+        if m and name is None:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            if re.match(r"^\.Lfunc_end\d+:", line):
+                out[name] = body
+                name = None
+                continue
+            s = line.strip()
+            if s and not s.startswith((";", ".", "//")) and not s.endswith(":"):
+                body.append(s.split(";")[0].strip())
+    return out
+
+
+def demangle(names):
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+    return dict(zip(names, r.stdout.splitlines()))
+
+
+FORBIDDEN = re.compile(r"^(v_pk_(add|mul|fma)_f32|v_fma_mix\w*)\b")
+FMA = re.compile(r"^(v_fma_f32|v_fmac_f32|v_fma_f64|v_fmac_f64|v_pk_fma_f16|v_fma_f16|v_fmac_f16)\b")
+
+
+def check_arithmetic(funcs):
+    """Returns a list of complaints (empty = fine)."""
+    bad = []
+    for name, body in funcs.items():
+        open_div = 0
+        for ins in body:
+            if FORBIDDEN.match(ins):
+                bad.append(f"{name}: {ins}")
+            elif ins.startswith("v_div_scale_f32"):
+                open_div += 1
+            elif ins.startswith("v_div_fixup_f32"):
+                open_div = max(0, open_div - 2)
+            elif FMA.match(ins) and open_div == 0:
+                bad.append(f"{name}: fused multiply-add outside a division sequence: {ins}")
+    return bad
+
+
+def check_group_start(funcs, names):
+    """Every deq_one<F, O, ...>: before its first tile load (global_load_dwordx4) it must contain, in this order, a
+    scalar ONE-dword load (the probe of the destination), a wait for it, the opaque `v_and_b32 v, 0, v` and the
+    v_readfirstlane that feeds the result into the source address."""
+    bad, seen = [], 0
+    for name, body in funcs.items():
+        if not names[name].startswith("void ggq::deq_one<"):
+            continue
+        seen += 1
+        try:
+            first_tile = next(i for i, s in enumerate(body) if s.startswith("global_load_dwordx4"))
+        except StopIteration:
+            bad.append(f"{names[name]}: no tile load found")
+            continue
+        head = body[:first_tile]
+        try:
+            i_probe = next(i for i, s in enumerate(head) if re.match(r"^s_load_dword\s+s\d+,", s))
+            i_wait = next(i for i, s in enumerate(head) if i > i_probe and s.startswith("s_waitcnt") and "lgkmcnt(0)" in s)
+            i_and = next(i for i, s in enumerate(head) if i > i_wait and re.match(r"^v_and_b32\s+v\d+, 0, v\d+", s))
+            next(i for i, s in enumerate(head) if i > i_and and s.startswith("v_readfirstlane_b32"))
+        except StopIteration:
+            bad.append(f"{names[name]}: the group start's scalar probe does not precede the first tile load")
+            continue
+        if any(s.startswith(("global_load_dword ", "flat_load_dword ", "buffer_load_dword ")) for s in head[:i_and]):
+            bad.append(f"{names[name]}: the probe went to the vector memory path")
+    if seen == 0:
+        bad.append("no deq_one kernel found")
+    return bad
+
+
+def resources(remarks):
+    """{mangled name: {field: int}} from -Rpass-analysis=kernel-resource-usage."""
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+# elements and packed bytes per block (gguf_amd/csrc/formats.h)
+BLOCK = {"Q4_0": (32, 18), "Q4_1": (32, 20), "Q5_0": (32, 22), "Q5_1": (32, 24), "Q8_0": (32, 34), "Q8_1": (32, 36),
+         "Q2K": (256, 84), "Q3K": (256, 110), "Q4K": (256, 144), "Q5K": (256, 176), "Q6K": (256, 210),
+         "Q8K": (256, 290), "IQ4NL": (32, 18), "IQ4XS": (256, 136)}
+
+
+def tile_lds_bytes(fmt, out):
+    """TileGeom<F, O>::LDS_SLOTS * 16 (gguf_amd/csrc/kernels.h): 512 threads x 2 stores of 16 bytes."""
+    epl = 4 if out == "OutF32" else 8
+    elems = 512 * epl * 2
+    n, b = BLOCK[fmt]
+    tbytes = elems // n * b
+    return ((tbytes + 15) // 16 + 2) * 16
+
+
+def check_resources(res, names):
+    bad, seen = [], 0
+    for name, r in res.items():
+        d = names.get(name, name)
+        m = re.match(r"^void ggq::(deq_one|deq_batch)<ggq::(\w+), ggq::(\w+),", d)
+        if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0 or r.get("SGPRs Spill", 0) != 0:
+            bad.append(f"{d}: scratch {r.get('ScratchSize')} B/lane, spills {r.get('VGPRs Spill')}/{r.get('SGPRs Spill')}")
+        if not m:
+            continue
+        seen += 1
+        if r.get("Occupancy") != 8:
+            bad.append(f"{d}: {r.get('Occupancy')} waves/SIMD (VGPRs {r.get('VGPRs')}), 8 expected")
+        want = tile_lds_bytes(m.group(2), m.group(3))
+        if r.get("LDS Size") != want:
+            bad.append(f"{d}: LDS {r.get('LDS Size')} bytes, tile geometry says {want}")
+    if seen < 2 * 14 * 3:
+        bad.append(f"only {seen} decode kernels in the resource report")
+    return bad

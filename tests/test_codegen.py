@@ -1,0 +1,59 @@
+"""The generated gfx950 code of libggq has the properties the design relies on (tests/isa_checks.py says which and
+why).  CPU only: hipcc cross-compiles the device side to assembly, no GPU is touched.  The last two tests remove one
+compiler flag each from the Makefile's set and expect the same checks to complain, so that a toolchain or Makefile
+change that loses a flag's effect cannot pass unnoticed."""
+import os
+import shutil
+
+import pytest
+
+import isa_checks as c
+
+pytestmark = pytest.mark.skipif(shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"),
+                                reason="needs make and hipcc")
+
+
+@pytest.fixture(scope="module")
+def shipped(tmp_path_factory):
+    s = str(tmp_path_factory.mktemp("isa") / "ggq_api.s")
+    remarks = c.compile_device(s)
+    funcs = c.functions(open(s).read())
+    res = c.resources(remarks)
+    names = c.demangle(sorted(set(funcs) | set(res)))
+    return funcs, res, names
+
+
+def test_flags_present():
+    flags = c.makefile_flags()
+    assert "-ffp-contract=off" in flags
+    assert "-Xclang -target-feature -Xclang -packed-fp32-ops" in flags
+    assert "--offload-arch=gfx950" in flags
+
+
+def test_no_packed_f32_no_mixed_fma_and_fma_only_in_divisions(shipped):
+    funcs, _, _ = shipped
+    assert len(funcs) > 100
+    assert c.check_arithmetic(funcs) == []
+
+
+def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
+    funcs, _, names = shipped
+    assert c.check_group_start(funcs, names) == []
+
+
+def test_decode_kernels_resources(shipped):
+    _, res, names = shipped
+    assert c.check_resources(res, names) == []
+
+
+@pytest.mark.parametrize("dropped, expect", [
+    ("-ffp-contract=off", "v_fma_mix"),
+    ("-Xclang -target-feature -Xclang -packed-fp32-ops", "v_pk_"),
+])
+def test_checks_notice_a_missing_flag(tmp_path, dropped, expect):
+    flags = c.makefile_flags()
+    assert dropped in flags
+    s = str(tmp_path / "sabotaged.s")
+    c.compile_device(s, flags_override=flags.replace(dropped, ""))
+    complaints = c.check_arithmetic(c.functions(open(s).read()))
+    assert complaints and any(expect in x for x in complaints)
