@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--gather", type=int, default=0, metavar="G",
                     help="N > 1: after the decode, time G all-gathers of the decoded shares (every rank ends with every "
                          "tensor; RCCL over xGMI).  Opt-in and reported on its own: the decode needs no exchange")
+    ap.add_argument("--layout", default="typed", choices=["typed", "scattered"],
+                    help="typed (default): a rank keeps the packed tensors of one block type back to back in one arena, "
+                         "and their outputs likewise, the way the library's file loader places them, so a launch plan sees "
+                         "one long run per type; scattered: every packed tensor is an allocation of its own")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -225,7 +229,7 @@ class Share:
     """One rank's pieces of the job: packed blocks and decoded output resident in HBM, one launch
     plan per block type (largest first)."""
 
-    def __init__(self, pieces, out_name, dev, seed_base, arena_bytes=None):
+    def __init__(self, pieces, out_name, dev, seed_base, arena_bytes=None, typed=True):
         import torch
         import gguf_amd as g
         from gguf_amd import synth
@@ -251,8 +255,22 @@ class Share:
         self.arena = torch.empty(max(at, arena_bytes or 0), dtype=torch.uint8, device=dev)
         self.dst_all = self.arena[:at].view(out_dt)
         self.by_type = {}
+        # typed layout: one packed arena per block type, the type's pieces back to back in share order (the caller
+        # passes the pieces sorted by type, so their outputs in `arena` are back to back as well)
+        packed_arena, packed_at = {}, {}
+        if typed:
+            for p in pieces:
+                packed_at[int(p.ggml_type)] = packed_at.get(int(p.ggml_type), 0) + p.blocks * block_bytes(p.ggml_type)
+            packed_arena = {ty: torch.empty(n, dtype=torch.uint8, device=dev) for ty, n in packed_at.items()}
+            packed_at = {ty: 0 for ty in packed_at}
         for i, (p, o) in enumerate(zip(pieces, offs)):
             src = synth.random_blocks_device(p.ggml_type, p.blocks, seed_base + i, dev)
+            if typed:
+                ty, n = int(p.ggml_type), src.numel()
+                slot = packed_arena[ty][packed_at[ty]:packed_at[ty] + n]
+                slot.copy_(src)
+                packed_at[ty] += n
+                src = slot
             dst = self.arena[o:o + p.elems * self.ob].view(out_dt)
             self.by_type.setdefault(int(p.ggml_type), []).append((p.ggml_type, src, dst))
         self.order = sorted(self.by_type, key=lambda t: -sum(x[2].numel() for x in self.by_type[t]))
@@ -486,10 +504,13 @@ def main():
     # ---- the job, dealt to ranks by the index partition -----------------------------
     base, items, label = job_items(args.workload, args.scaling, world)
     shares = shard.partition(items, world, out_bytes=4 if args.out == "f32" else 2)
+    typed = args.layout == "typed"
+    if typed:
+        shares = [shard.by_type(s) for s in shares]
     gathering = args.gather > 0 and world > 1
     where, padded = shard.arena_layout(shares, 4 if args.out == "f32" else 2)
     try:
-        share = Share(shares[rank], args.out, dev, 0xC0FFEE04 + 100000 * rank, padded if gathering else None)
+        share = Share(shares[rank], args.out, dev, 0xC0FFEE04 + 100000 * rank, padded if gathering else None, typed)
     except MemoryError as e:
         sys.exit(f"rank {rank}: {e}")
     ob = share.ob
@@ -569,6 +590,7 @@ def main():
     order = share.order
     dom_elems_by_type = {ty: sum(x[2].numel() for x in share.by_type[ty]) for ty in share.order}
     launches = share.launches
+    plan_launches = [b.launches for _, b in share.plans]
 
     # secondary: weak scaling (every rank one whole set), when the headline is strong scaling
     weak = None
@@ -578,8 +600,9 @@ def main():
             share = None
             torch.cuda.empty_cache()
             _, w_items, w_label = job_items(args.workload, "weak", world)
-            w_share = Share(shard.partition(w_items, world, out_bytes=ob)[rank], args.out, dev,
-                            0xC0FFEE04 + 100000 * rank)
+            w_pieces = shard.partition(w_items, world, out_bytes=ob)[rank]
+            w_share = Share(shard.by_type(w_pieces) if typed else w_pieces, args.out, dev,
+                            0xC0FFEE04 + 100000 * rank, None, typed)
             w_elapsed, _, _ = timed_resident(w_share, args.steps, args.warmup, args.settle_ms, fence, with_events=False)
             w_elapsed = max_over_ranks(w_elapsed)
             _, w_pout, w_nel = synth.workload_bytes(w_items, ob)
@@ -632,13 +655,18 @@ def main():
             "config": {"workload": label + (f" (REHEARSAL: {world} ranks share {ndev} GPU)" if shared else ""),
                        "tensors": len(items), "elements": total_elems, "packed_bytes": pin,
                        "decoded_bytes": pout, "partition": "index (LPT), no collective",
+                       "layout": "typed: per rank, the packed tensors of a block type back to back in HBM and their outputs "
+                                 "likewise (one run per type)" if typed else "scattered: one allocation per packed tensor",
                        "kernel_launches_per_step": launches},
             "melem_per_s": round(total_elems / per / 1e6, 1),
             "packed_GBps": round(pin / per / 1e9, 2),
             "algorithmic_GBps": round((pin + pout) / per / 1e9, 2),
-            "kernels": [{"type": GGmlType(ty).name, "elements": dom_elems_by_type[ty],
+            "kernels": [{"type": GGmlType(ty).name, "elements": dom_elems_by_type[ty], "launches": plan_launches[k],
                          "avg_ms": round(kern_ms[k], 4)} for k, ty in enumerate(order)],
-            "roofline": {"bound": "hbm", "kernel": f"deq_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)",
+            "roofline": {"bound": "hbm",
+                         "kernel": f"deq_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)" if plan_launches[0] == 1 else
+                                   f"the {GGmlType(dom_ty).name} -> {args.out} launch plan (rank 0): deq_batch over the tile "
+                                   f"table + {plan_launches[0] - 1} deq_one launches for tensors of 64 Mi elements and more",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,

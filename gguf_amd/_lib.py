@@ -73,6 +73,7 @@ SYMBOLS = {
     "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),
     "ggq_upload_async": (_int, [_vp, _vp, _vp, _sz]),
     "ggq_ctx_fence": (_int, [_vp, _vp]),
+    "ggq_ctx_wait_stream": (_int, [_vp, _vp]),
     "ggq_dequantize_noalloc": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
     "ggq_sync": (_int, [_vp]),
     "ggq_ctx_destroy": (None, [_vp]),

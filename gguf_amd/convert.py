@@ -848,27 +848,44 @@ class _Producer:
             with torch.cuda.device(self._device):
                 ctx = Context(self._device, 64 << 20)
 
+                stream = torch.cuda.Stream()
+
                 def up(arr):
+                    # The allocator hands out blocks freed on `stream` while kernels queued there may still read
+                    # them (safe for later work on `stream` only); the copy runs on the context's streams, so it
+                    # is ordered behind `stream` first.
                     d = torch.empty(arr.size, dtype=torch.uint8, device=dev)
+                    ctx.wait_stream(stream.cuda_stream)
                     ctx.upload_async(d, arr)
                     ctx.sync()
                     return d
 
-                stream = torch.cuda.Stream()
                 with torch.cuda.stream(stream):
                     for unit in self._units():
                         if isinstance(unit, list):
-                            srcs, outs = [], []
-                            for name, t in unit:
-                                c = t.data
-                                d = torch.empty(c.src.arr.size, dtype=torch.uint8, device=dev)
-                                ctx.upload_async(d, c.src.arr)
-                                srcs.append(d)
-                                n = c.src.arr.size // block_bytes(c.from_ty) * block_elems(c.from_ty)
-                                outs.append(torch.empty(n, dtype=_torch_dtype(c.to_ty), device=dev))
-                            by_out = {}
-                            for (name, t), sd, od in zip(unit, srcs, outs):
-                                by_out.setdefault(t.data.to_ty, []).append((t.data.from_ty, sd, od))
+                            # Typed layout: the unit's tensors of one (source type, output type) pair sit back to
+                            # back in one packed arena and in one output arena, in file order, so that the launch
+                            # plan sees one long run per pair (ggq_batch_create merges adjacent tensors).
+                            pairs = {}
+                            for k, (name, t) in enumerate(unit):
+                                pairs.setdefault((int(t.data.from_ty), int(t.data.to_ty)), []).append(k)
+                            ctx.wait_stream(stream.cuda_stream)
+                            outs, by_out, keep = [None] * len(unit), {}, []
+                            for (from_ty, to_ty), members in pairs.items():
+                                nbytes = sum(unit[k][1].data.src.arr.size for k in members)
+                                nelems = nbytes // block_bytes(from_ty) * block_elems(from_ty)
+                                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                                decoded = torch.empty(nelems, dtype=_torch_dtype(to_ty), device=dev)
+                                keep += [packed, decoded]
+                                at_b = at_e = 0
+                                for k in members:
+                                    arr = unit[k][1].data.src.arr
+                                    n = arr.size // block_bytes(from_ty) * block_elems(from_ty)
+                                    ctx.upload_async(packed[at_b:at_b + arr.size], arr)
+                                    outs[k] = decoded[at_e:at_e + n]
+                                    by_out.setdefault(to_ty, []).append((from_ty, packed[at_b:at_b + arr.size], outs[k]))
+                                    at_b += arr.size
+                                    at_e += n
                             plans = [Batch(v, k) for k, v in by_out.items()]     # built while the last copies fly
                             ctx.sync()
                             for p in plans:
@@ -879,7 +896,7 @@ class _Producer:
                                     return
                             for p in plans:
                                 p.close()
-                            del srcs, outs
+                            del outs, by_out, keep
                         else:
                             name, t = unit
                             try:

@@ -153,6 +153,33 @@ const uint64_t kMaxGrid = [] {
     return lim;
 }();
 
+// Launch plans (ggq_batch_*) are hybrids.  Tensors of one type that follow each other in the caller's table AND in
+// memory -- the next one's blocks start where the previous one's end, and so do their outputs -- are one run: blocks
+// are independent, so a run decodes as one long tensor.  A run of at least this many elements whose single-tensor
+// schedule has a group start (schedule.h) leaves the plan's tile table and gets a launch of its own: the table
+// kernel cannot take the group start and runs 4-7 points of the roofline below the single-tensor kernel for those
+// (type, output) pairs, while a launch costs 3-4 us of ramp and drain (measured on 235 Mi-element tensors: 202
+// launches of their own bring the Llama-70B set's Q4_K -> f16 part from 23.28 to 23.07 ms, where 22.3 ms were to
+// be had without the launch costs).  A loader that places the tensors of a type back to back therefore gets one
+// launch per type at the single-tensor kernel's rate.
+// GGQ_HYBRID_MIN_ELEMS (environment, read once) moves the limit: 0 switches the hybrid off, small values let tests
+// reach both routes with small tensors.
+const uint64_t kHybridMinElems = [] {
+    uint64_t lim = 64ull << 20;
+    if (const char *e = std::getenv("GGQ_HYBRID_MIN_ELEMS")) {
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        lim = v == 0 ? ~0ull : v;
+    }
+    return lim;
+}();
+
+// GGQ_HYBRID_ANY=1 (environment, read once; measurement knob): runs above the limit get their own launch whatever
+// their schedule.
+const bool kHybridAny = [] {
+    const char *e = std::getenv("GGQ_HYBRID_ANY");
+    return e && e[0] == '1';
+}();
+
 // GGQ_WIDE_INDEX=1 (environment, read once): take the 64-bit index kernels also for small tensors, so that tests
 // reach them.
 const bool kWideIndex = [] {
@@ -426,6 +453,8 @@ struct ggq_batch {
         uint64_t n;
     };
     std::vector<Plain> plain;
+    // runs of adjacent block-format tensors large enough for a launch of their own (kHybridMinElems)
+    std::vector<Plain> single;
     TileRef *d_table = nullptr;
 };
 
@@ -439,6 +468,7 @@ struct ggq_ctx {
     hipStream_t stream[SLOTS] = {};
     hipEvent_t done[SLOTS] = {};
     hipEvent_t fence[SLOTS] = {};   // ggq_ctx_fence: one per stream, re-recorded by every fence
+    hipEvent_t gate = nullptr;      // ggq_ctx_wait_stream: recorded on the caller's stream, awaited by both streams
     uint8_t *h_in[SLOTS] = {};
     uint8_t *d_in[SLOTS] = {};
     uint8_t *h_out[SLOTS] = {};
@@ -564,6 +594,7 @@ void ctx_free(ggq_ctx *c) {
         if (c->fence[s]) (void)hipEventDestroy(c->fence[s]);
         if (c->stream[s]) (void)hipStreamDestroy(c->stream[s]);
     }
+    if (c->gate) (void)hipEventDestroy(c->gate);
     delete c;
 }
 
@@ -594,6 +625,7 @@ ggq_status ctx_make(int device, size_t in_cap, size_t out_cap, ggq_ctx **out) {
             ok = ok && hip_ok(hipMalloc((void **)&c->d_out[s], out_cap), "hipMalloc");
         }
     }
+    ok = ok && hip_ok(hipEventCreateWithFlags(&c->gate, hipEventDisableTiming), "hipEventCreate");
     (void)hipSetDevice(prev);
     if (!ok) { ctx_free(c); return GGQ_DEVICE; }
     *out = c;
@@ -999,16 +1031,42 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
     b->cus = di.cus;
     b->out_ty = out_ty;
 
-    // group by type, keeping the caller's order inside a group
+    // Route every tensor (the rule is stated at kHybridMinElems).  F16 / BF16 sources are widened one launch each.
+    // Block types: adjacent tensors are merged into runs; a run goes to a launch of its own or, as ONE entry, into
+    // the tile table of its type.
+    struct Run { uint32_t ty; uint64_t src, dst, blocks; };
+    std::vector<Run> runs;                 // table entries, in the caller's order
     std::vector<uint32_t> types;
-    for (size_t i = 0; i < count; ++i) {
-        uint32_t ty = tensors[i].ggml_type;
-        if (tensors[i].blocks == 0) continue;
-        if (ty == GGQ_TYPE_F16 || ty == GGQ_TYPE_BF16) {
-            b->plain.push_back({ty, tensors[i].d_src, tensors[i].d_dst, tensors[i].blocks});
-            continue;
+    {
+        const uint64_t ob = out_bytes(out_ty);
+        std::vector<Run> merged;
+        for (size_t i = 0; i < count; ++i) {
+            const uint32_t ty = tensors[i].ggml_type;
+            if (tensors[i].blocks == 0) continue;
+            if (ty == GGQ_TYPE_F16 || ty == GGQ_TYPE_BF16) {
+                b->plain.push_back({ty, tensors[i].d_src, tensors[i].d_dst, tensors[i].blocks});
+                continue;
+            }
+            const TypeInfo *ti = type_info(ty);
+            const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
+            // the run of this type that was extended last, if this tensor continues it
+            Run *prev = nullptr;
+            for (size_t k = merged.size(); k-- > 0;)
+                if (merged[k].ty == ty) { prev = &merged[k]; break; }
+            if (prev && prev->src + prev->blocks * ti->bytes == src && prev->dst + prev->blocks * ti->elems * ob == dst)
+                prev->blocks += tensors[i].blocks;
+            else
+                merged.push_back({ty, src, dst, tensors[i].blocks});
         }
-        if (std::find(types.begin(), types.end(), ty) == types.end()) types.push_back(ty);
+        for (const Run &r : merged) {
+            const uint64_t elems = r.blocks * type_info(r.ty)->elems;
+            if (elems >= kHybridMinElems && (kHybridAny || pick_prefetch(r.ty, out_ty, false, elems).wait != 0)) {
+                b->single.push_back({r.ty, (const void *)(uintptr_t)r.src, (void *)(uintptr_t)r.dst, r.blocks});
+                continue;
+            }
+            runs.push_back(r);
+            if (std::find(types.begin(), types.end(), r.ty) == types.end()) types.push_back(r.ty);
+        }
     }
     // One TileRef per tile, tensors of one type consecutive (caller's order inside a type).  The host only
     // writes one descriptor per tensor; a small kernel per group expands them into the table.
@@ -1022,12 +1080,11 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
         const HostGeom hg = host_geom(ti, out_ty);
         ggq_batch::Group g{ty, total_tiles, 0};
         Span sp{descs.size(), 0};
-        for (size_t i = 0; i < count; ++i) {
-            if (tensors[i].ggml_type != ty || tensors[i].blocks == 0) continue;
-            const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
-            if (src >> 48) { ggq_batch_destroy(b); return GGQ_INVALID; }
-            descs.push_back({src, dst, tensors[i].blocks, g.ntiles});
-            g.ntiles += (tensors[i].blocks + hg.blocks - 1) / hg.blocks;
+        for (const Run &r : runs) {
+            if (r.ty != ty) continue;
+            if (r.src >> 48) { ggq_batch_destroy(b); return GGQ_INVALID; }
+            descs.push_back({r.src, r.dst, r.blocks, g.ntiles});
+            g.ntiles += (r.blocks + hg.blocks - 1) / hg.blocks;
             ++sp.ndesc;
         }
         total_tiles += (g.ntiles + 63) / 64 * 64;      // record_slot() permutes within runs of 64
@@ -1088,6 +1145,10 @@ ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
         }
         if (rc != GGQ_OK) return rc;
     }
+    for (const auto &p : b->single) {
+        ggq_status rc = launch_out(p.ty, b->out_ty, p.dst, p.src, p.n, b->cus, st);
+        if (rc != GGQ_OK) return rc;
+    }
     for (const auto &p : b->plain) {
         ggq_status rc = launch_out(p.ty, b->out_ty, p.dst, p.src, p.n, b->cus, st);
         if (rc != GGQ_OK) return rc;
@@ -1095,7 +1156,9 @@ ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
     return GGQ_OK;
 }
 
-size_t ggq_batch_launches(const ggq_batch *b) { return b ? b->groups.size() + b->plain.size() : 0; }
+size_t ggq_batch_launches(const ggq_batch *b) {
+    return b ? b->groups.size() + b->single.size() + b->plain.size() : 0;
+}
 
 void ggq_batch_destroy(ggq_batch *b) {
     if (!b) return;
@@ -1258,6 +1321,19 @@ ggq_status ggq_ctx_fence(ggq_ctx *c, void *hip_stream) {
             !hip_ok(hipStreamWaitEvent((hipStream_t)hip_stream, c->fence[s], 0), "hipStreamWaitEvent"))
             rc = GGQ_DEVICE;
     }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+ggq_status ggq_ctx_wait_stream(ggq_ctx *c, void *hip_stream) {
+    if (!c) return GGQ_INVALID;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(c->device));
+    ggq_status rc = GGQ_OK;
+    if (!hip_ok(hipEventRecord(c->gate, (hipStream_t)hip_stream), "hipEventRecord")) rc = GGQ_DEVICE;
+    for (int s = 0; s < ggq_ctx::SLOTS && rc == GGQ_OK; ++s)
+        if (!hip_ok(hipStreamWaitEvent(c->stream[s], c->gate, 0), "hipStreamWaitEvent")) rc = GGQ_DEVICE;
     (void)hipSetDevice(prev);
     return rc;
 }

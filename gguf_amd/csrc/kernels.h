@@ -149,7 +149,10 @@ struct Prefetch {
 // effect: the same probe forced onto the vector path (measured) turns the gain into a loss of 10-18 points.  The
 // description above is therefore a model that fits the measurements, not an established mechanism.
 __device__ __forceinline__ uint32_t group_wait(const void *group_dst) {
-    const uint32_t seen = *(const uint32_t *)group_dst;
+    // the address is named as global memory (address space 1) outright: a pointer of unknown address space -- one
+    // assembled from integers, as in deq_seg -- would be loaded with a flat (vector) instruction
+    typedef const __attribute__((address_space(1))) uint32_t *GlobalU32;
+    const uint32_t seen = *(GlobalU32)(uintptr_t)group_dst;
     uint32_t zero;
     asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(seen));
     return __builtin_amdgcn_readfirstlane(zero);

@@ -61,7 +61,11 @@ inline Prefetch prefetch_for(uint32_t ty, uint32_t out_ty, bool batch, uint64_t 
         }
         if (!large) return {0, 0};
         switch (ty) {
-        case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: case GGQ_TYPE_IQ4NL: case GGQ_TYPE_Q4_0: return {1, 2048, 6};
+        // groups of 64 up to 16 Gi elements, of 16 beyond: measured on single runs of Q4_K -> f16 (tools/
+        // probe_size_scaling.py, % of 8 TB/s at 2 / 4 / 8 / 16 / 32 / 48 Gi elements): groups of 64 83.1 / 83.7 / 83.7 /
+        // 83.3-83.8 / 80.1-81.0 / 80.6, groups of 16 82.8 / 82.7 / 82.9 / 83.0-83.5 / 83.6-83.8 / 83.8
+        case GGQ_TYPE_Q4K: case GGQ_TYPE_IQ4XS: case GGQ_TYPE_IQ4NL: case GGQ_TYPE_Q4_0:
+            return elems > (16ull << 30) ? Prefetch{1, 2048, 4} : Prefetch{1, 2048, 6};
         case GGQ_TYPE_Q5K: return {1, 1280, 6};
         case GGQ_TYPE_Q4_1: case GGQ_TYPE_Q5_0: return {1, 1280, 5};
         case GGQ_TYPE_Q6K: case GGQ_TYPE_Q5_1: return {1, 1280, 4};

@@ -364,14 +364,22 @@ _ctx_cache = threading.local()
 
 
 def _thread_context(device, staging_bytes):
-    """One streamed-upload context per (thread, device, staging size), kept for the life of the thread: creating
-    one pins its staging memory, which costs about as long as decoding a 1 B-parameter model."""
+    """One streamed-upload context per (thread, device, staging size): creating one pins its staging memory,
+    which costs about as long as decoding a 1 B-parameter model.  It stays (staging_bytes of page-locked host
+    memory plus as much device memory) until the thread calls close_thread_contexts() or ends."""
     from .quants import Context
     cache = _ctx_cache.__dict__.setdefault("ctx", {})
     key = (int(device), int(staging_bytes))
     if key not in cache:
         cache[key] = Context(device, staging_bytes)
     return cache[key]
+
+
+def close_thread_contexts():
+    """Release the calling thread's cached upload contexts (their pinned and device staging memory)."""
+    cache = _ctx_cache.__dict__.pop("ctx", {})
+    for c in cache.values():
+        c.close()
 
 
 def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None, group_bytes=1 << 30,
@@ -382,8 +390,12 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
 
     The packed bytes are streamed host -> device through one Context (pinned staging, helper
     threads); tensors are gathered into groups of about `group_bytes` packed bytes and each group is
-    decoded by ONE launch plan -- one kernel launch per block type present, not one per tensor --
-    while the next group's bytes are still on their way.  `stats`, if a dict, receives the counts."""
+    decoded by ONE launch plan while the next group's bytes are still on their way.  Inside a group the
+    tensors of one block type are placed back to back, in the packed arena and in the output (the returned
+    tensors of a group and type are views of one allocation, which lives as long as any of them), so the
+    plan sees one long run per type and decodes it with one launch at the single-tensor kernel's rate.  A
+    group's packed bytes are released as soon as its plan is enqueued: peak device memory is the decoded
+    tensors plus about two groups of packed bytes.  `stats`, if a dict, receives the counts."""
     import torch
     from .quants import Batch, SUPPORTED
     dt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[out]
@@ -397,21 +409,41 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
     def flush(group):
         if not group:
             return
-        offs, total = [], 0
-        for t, _ in group:
+        # Memory that torch's allocator hands out now may be a block this function released a moment ago (an
+        # earlier group's packed arena) that a plan queued on the current stream is still reading: the uploads
+        # below run on the context's streams, so they are ordered behind the current stream explicitly.
+        ctx.wait_stream()
+        first = {}
+        for t in group:
+            first.setdefault(int(t.ty), len(first))
+        group = sorted(group, key=lambda t: first[int(t.ty)])        # stable: file order inside a type
+        offs, total, elems = [], 0, {}
+        for k, t in enumerate(group):
+            if k and int(group[k - 1].ty) != int(t.ty):
+                total = (total + 31) & ~31
             offs.append(total)
-            total += (t.nbytes + 31) & ~31
+            total += t.nbytes
+            elems[int(t.ty)] = elems.get(int(t.ty), 0) + t.numel
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
-        for (t, _), o in zip(group, offs):
+        outs = {ty: torch.empty(n, dtype=dt, device=dev) for ty, n in elems.items()}
+        at = {ty: 0 for ty in elems}
+        table = []
+        for t, o in zip(group, offs):
             ctx.upload_async(arena[o:o + t.nbytes], t.bytes())
+            ty = int(t.ty)
+            dst = outs[ty][at[ty]:at[ty] + t.numel]
+            at[ty] += t.numel
+            res[t.name] = dst
+            table.append((t.ty, arena[o:o + t.nbytes], dst))
         # the plan needs only addresses: it is built while the last copies are still in flight
-        b = Batch([(t.ty, arena[o:o + t.nbytes], dst) for (t, dst), o in zip(group, offs)], out_ty)
+        b = Batch(table, out_ty)
         ctx.fence()                     # the plan waits on the device for this group's copies; the host goes on
         b.run()                         # staging the next group meanwhile
-        plans.append((b, arena))
+        plans.append(b)                 # (the plan keeps its tensors -- and with them the arena -- until it is dropped)
         counts["groups"] += 1
         counts["launches"] += b.launches
         counts["packed_bytes"] += total
+        b.release_tensors()             # enqueued: the arena goes back to the allocator, stream-ordered
 
     try:
         with torch.cuda.device(device):
@@ -422,15 +454,14 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
                 if not t.ptr:
                     continue
                 if t.ty == GGmlType.F32:
+                    ctx.wait_stream()
                     dst = torch.empty(t.numel, dtype=torch.float32, device=dev)
                     ctx.upload_async(dst.view(torch.uint8), t.bytes())
                     res[t.name] = dst
                     continue
                 if t.ty not in supported:
                     continue
-                dst = torch.empty(t.numel, dtype=dt, device=dev)
-                res[t.name] = dst
-                group.append((t, dst))
+                group.append(t)
                 held += t.nbytes
                 counts["tensors"] += 1
                 if held >= group_bytes:
@@ -441,7 +472,7 @@ def dequantize_file(gguf, out="f32", device=0, staging_bytes=64 << 20, only=None
             torch.cuda.synchronize()
     finally:
         ctx.sync()                      # also on the error path: nothing of this call may still be in flight
-        for b, _ in plans:
+        for b in plans:
             b.close()
     if stats is not None:
         stats.update(counts)

@@ -290,6 +290,12 @@ class Batch:
             stream = torch.cuda.current_stream().cuda_stream
         check(lib.ggq_batch_run(self._h, stream))
 
+    def release_tensors(self):
+        """Drop the plan's references to its tensors.  For a plan that will not run again, once its last run is
+        enqueued: with a stream-ordered allocator (torch's) the memory can then be handed out again for later work
+        on the same stream while the plan's kernels are still queued."""
+        self._keep = None
+
     def close(self):
         if self._h:
             lib.ggq_batch_destroy(self._h)
@@ -340,6 +346,15 @@ class Context:
             import torch
             stream = torch.cuda.current_stream().cuda_stream
         check(lib.ggq_ctx_fence(self._h, stream))
+
+    def wait_stream(self, stream=None):
+        """Work enqueued on this context from now on waits, on the device, for everything enqueued on `stream`
+        (default: torch's current stream) so far.  Call it before uploading into memory that torch's allocator may
+        have handed out before: the allocator orders reuse only on the stream the memory was allocated on."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib.ggq_ctx_wait_stream(self._h, stream))
 
     def sync(self):
         check(lib.ggq_sync(self._h))

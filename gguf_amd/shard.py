@@ -85,6 +85,17 @@ def partition(items, world_size, row_elems=None, out_bytes=4):
     return shares
 
 
+def by_type(share):
+    """A share's pieces with those of one block type next to each other (types in order of first appearance,
+    tensor order kept inside a type).  A rank that lays its packed pieces and its outputs out in THIS order has
+    every type's blocks and every type's outputs contiguous in memory, which a launch plan decodes as one long
+    tensor per type (ggq_batch_create merges adjacent tensors into runs)."""
+    first = {}
+    for p in share:
+        first.setdefault(p.ggml_type, len(first))
+    return sorted(share, key=lambda p: (first[p.ggml_type], p.tensor, p.block_begin))
+
+
 def imbalance(shares, out_bytes=4):
     """max rank load / mean rank load (1.0 = perfect)."""
     loads = [sum(p.blocks * (block_elems(p.ggml_type) * out_bytes + block_bytes(p.ggml_type)) for p in s)

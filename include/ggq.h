@@ -162,7 +162,11 @@ ggq_status ggq_scale_device(uint32_t ggml_type, void *d_dst, const void *d_src, 
  * launch per block type present, instead of one per tensor.  Stands in for the
  * loop over tensors that the reference's cast operator performs
  * (xtask/src/utils/operator/cast.rs:73-90), each iteration of which ends in
- * dequantize_slice. */
+ * dequantize_slice.  A plan is a hybrid: tensors of 64 Mi elements and more whose
+ * (type, output) pair decodes faster on its own than through the shared launch
+ * (2-byte outputs of most types, the 8-bit types with 4-byte output) get one launch
+ * each inside the plan; like ggq_dequantize_device, those launches read one dword of
+ * d_dst, so every d_dst must be readable as well as writable. */
 typedef struct ggq_tensor {
     uint32_t ggml_type;   /* block type of src                      */
     uint32_t reserved;    /* must be 0                              */
@@ -217,6 +221,12 @@ ggq_status ggq_upload_async(ggq_ctx *ctx, void *d_dst, const void *h_src, size_t
  * The host does not wait, so it can go on staging the next tensors while a plan for the ones just uploaded
  * (ggq_batch_run on hip_stream) waits its turn on the device.  No counterpart in the reference. */
 ggq_status ggq_ctx_fence(ggq_ctx *ctx, void *hip_stream);
+/* The other direction: copies and decodes enqueued on the context AFTER this call start only when everything
+ * enqueued on `hip_stream` so far has completed.  For a caller whose destination memory comes from a
+ * stream-ordered pool (torch's caching allocator): a block the pool hands out again may still be read by work
+ * queued on the caller's stream, and the context's streams are not ordered behind that stream by themselves.
+ * The host does not wait.  No counterpart in the reference. */
+ggq_status ggq_ctx_wait_stream(ggq_ctx *ctx, void *hip_stream);
 ggq_status ggq_sync(ggq_ctx *ctx);
 void ggq_ctx_destroy(ggq_ctx *ctx);
 

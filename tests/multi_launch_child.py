@@ -1,5 +1,8 @@
-"""Run by test_gpu_multi_launch.py in a child process whose environment sets GGQ_MAX_GRID=3, so that
-every entry point that splits large inputs over several kernel launches does so on small inputs.
+"""Run by test_gpu_multi_launch.py in a child process whose environment sets GGQ_MAX_GRID=3 (or leaves the grid
+limit alone), so that every entry point that splits large inputs over several kernel launches does so on small
+inputs, and GGQ_HYBRID_MIN_ELEMS=20000, so that launch plans send runs of adjacent tensors with 20000 elements and
+more through launches of their own and the rest through the tile table, as they do for runs of 64 Mi elements by
+default; GGQ_PREFETCH may force a schedule (with or without group start) onto every kernel.
 Compares everything with the CPU oracle / numpy and prints OK."""
 import os
 import sys
@@ -15,9 +18,18 @@ import gguf_amd as g  # noqa: E402
 import oracle as o  # noqa: E402
 from gguf_amd import rearrange as R, synth  # noqa: E402
 from test_gpu_rearrange import np_permute_qk  # noqa: E402
+import util  # noqa: E402
 from util import same_bits, same_bits16  # noqa: E402
 
-assert os.environ.get("GGQ_MAX_GRID") == "3"
+MAX_GRID = int(os.environ.get("GGQ_MAX_GRID", str(1 << 22)))
+assert MAX_GRID in (3, 1 << 22) and os.environ.get("GGQ_HYBRID_MIN_ELEMS") == "20000"
+FORCED = [int(x) for x in os.environ["GGQ_PREFETCH"].split(",")] if os.environ.get("GGQ_PREFETCH") else None
+
+
+def plan_entries(tensors, ob):
+    return util.plan_entries(tensors, ob, forced=FORCED, min_elems=20000)
+
+
 o.build()
 t = torch
 
@@ -51,6 +63,87 @@ t.cuda.synchronize()
 for (_, _, d), p in zip(tensors, packed):
     assert same_bits(d.cpu().numpy(), o.dequantize(12, p, threads=4)), "batch"
 b.close()
+
+# hybrid plans: tensors of every route in one plan (tile table, launches of their own, widening), several types,
+# 2- and 4-byte outputs, odd source offsets, ragged last tiles, empty tensors; sizes straddle the limit (20000
+# elements) on both sides.  Third field: the tensor sits right behind the previous tensor of its type, in the packed
+# arena and in the output arena, so the two form one run (runs reach the limit that their tensors alone do not).
+SPEC = ((12, 19968), (12, 20224), (14, 8192 * 5 + 256), (14, 256), (8, 20000 - 32), (8, 20000), (2, 32 * 2000),
+        (12, 0), (13, 256 * 400), (1, 30000), (20, 32 * 625), (12, 256 * 3), (12, 8192 * 3, True), (14, 256 * 33, True),
+        (12, 256, True), (12, 256 * 40, True), (12, 256 * 31), (12, 256 * 90, True), (12, 512), (12, 256 * 77, True),
+        (12, 256 * 5, True), (8, 32 * 700), (8, 32, True), (15, 256 * 100), (23, 256 * 81), (6, 32 * 1000),
+        (7, 32 * 999), (3, 32 * 640), (9, 32 * 641), (3, 32 * 3, True), (3, 32 * 77, True))
+for out_dt, o_out, o_ty in ((t.float32, o.F32, g.GGmlType.F32), (t.float16, o.F16, g.GGmlType.F16),
+                            (t.bfloat16, o.BF16, g.GGmlType.BF16)):
+    ob = 4 if out_dt == t.float32 else 2
+    tensors, packed, tail = [], [], {}          # tail[type] = (packed arena, bytes used, output arena, elements used)
+    for i, spec in enumerate(SPEC):
+        ty, elems, adj = (spec + (False,))[:3]
+        blocks = elems // g.block_elems(ty)
+        p = synth.random_blocks(ty, blocks, 170 + i)
+        if adj:
+            raw, used_b, out, used_e = tail[ty]
+        else:
+            off = (3 * i) % 16 if ty not in (1, 30) else 8
+            raw, used_b = t.empty(off + (1 << 20), dtype=t.uint8, device="cuda"), off
+            out, used_e = t.full((1 << 20,), float("nan"), dtype=out_dt, device="cuda"), 0
+        src = raw[used_b:used_b + p.size]
+        src.copy_(t.from_numpy(p))
+        dst = out[used_e:used_e + elems]
+        tail[ty] = (raw, used_b + p.size, out, used_e + elems)
+        tensors.append((ty, src, dst))
+        packed.append(p)
+    b = g.Batch(tensors, o_ty)
+    want_entries = plan_entries(SPEC, ob)
+    assert b.launches == want_entries, ("hybrid plan entries", b.launches, want_entries, FORCED, MAX_GRID)
+    for rep in range(2):
+        b.run()
+    t.cuda.synchronize()
+    for (ty, _, d), p in zip(tensors, packed):
+        want = o.dequantize(ty, p, o_out, threads=4)
+        ok = same_bits(d.cpu().numpy(), want) if out_dt == t.float32 else \
+            same_bits16(bits16(d), want, "f16" if out_dt == t.float16 else "bf16")
+        assert ok, ("hybrid plan", ty, d.numel(), out_dt)
+    for ty, (raw, used_b, out, used_e) in tail.items():         # nothing written behind a run's last element
+        rest = out[used_e:used_e + 4096]
+        assert bool(t.isnan(rest.float()).all()), ("hybrid plan wrote past a run", ty)
+    b.close()
+
+# whole-file decode: the loader places a group's tensors of one type back to back (packed and decoded), so every
+# type is one run; runs above the limit get launches of their own
+import tempfile  # noqa: E402
+from gguf_amd import gguf as G  # noqa: E402
+fspec = [("a.weight", 12, (2048, 6)), ("n0.weight", 0, (2048,)), ("b.weight", 14, (2048, 3)), ("c.weight", 12, (2048, 5)),
+         ("d.weight", 8, (2048, 4)), ("e.weight", 14, (2048, 9)), ("f.weight", 1, (2048, 2)), ("g.weight", 12, (256, 3)),
+         ("h.weight", 8, (2048, 7)), ("i.weight", 10, (2048, 12)), ("j.weight", 20, (2048, 3))]
+ft, fpacked = [], {}
+for i, (name, ty, shape) in enumerate(fspec):
+    n = int(np.prod(shape))
+    data = np.random.default_rng(i).standard_normal(n).astype(np.float32).view(np.uint8) if ty == 0 else \
+        synth.random_blocks(ty, n // g.block_elems(ty), 300 + i)
+    fpacked[name] = (ty, data)
+    ft.append((name, ty, shape, data))
+with tempfile.TemporaryDirectory() as td:
+    path = os.path.join(td, "typed.gguf")
+    open(path, "wb").write(G.build_gguf({"general.architecture": "llama"}, ft))
+    with G.GGuf(path) as f:
+        for out, o_out in (("f32", o.F32), ("f16", o.F16)):
+            stats = {}
+            res = G.dequantize_file(f, out=out, staging_bytes=1 << 20, stats=stats)
+            per_type = {}
+            for name, ty, shape in fspec:
+                if ty != 0:
+                    per_type[ty] = per_type.get(ty, 0) + int(np.prod(shape))
+            want_entries = plan_entries([(ty, n) for ty, n in per_type.items()], 4 if out == "f32" else 2)
+            assert (stats["groups"], stats["launches"]) == (1, want_entries), (stats, want_entries, FORCED)
+            for name, (ty, data) in fpacked.items():
+                if ty == 0:
+                    assert np.array_equal(res[name].cpu().numpy().view(np.uint8), data)
+                    continue
+                want = o.dequantize(ty, data, o_out, threads=4)
+                ok = same_bits(res[name].cpu().numpy(), want) if out == "f32" else same_bits16(bits16(res[name]), want, "f16")
+                assert ok, ("file decode", name, out)
+    G.close_thread_contexts()
 
 # a group of more than 3 * 256 tiles: the tile table itself is built by several launches
 p = synth.random_blocks(12, 16 * 1700 + 3, 79)

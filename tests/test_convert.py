@@ -263,3 +263,21 @@ def test_merge_split_permute_on_device(tmp_path):
         qkv = np.concatenate([q, k, src[f"blk.{i}.attn_v.weight"][3]])
         assert both[f"blk.{i}.attn_qkv.weight"][0] == 0
         assert np.array_equal(both[f"blk.{i}.attn_qkv.weight"][2], O.dequantize(int(T.Q8_0), qkv).view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_concat_of_cast_parts_of_equal_size(tmp_path):
+    """cast, then merge: every merged tensor is a Concat of Cast(Borrowed) parts, evaluated one part after the other.
+    A part's packed upload is freed as soon as its decode is enqueued, and the next part's upload (k and v have the
+    same size, so the allocator offers the very same block) runs on the upload context's streams: it must be ordered
+    behind the decode that still reads the block.  Repeated, because the window is a few microseconds."""
+    from oracle import oracle as O
+    nh, nkvh, dh = 4, 2, 8
+    p, src = _attn_model(tmp_path, nh=nh, nkvh=nkvh, dh=dh)
+    for rep in range(6):
+        got = _read_all(C.convert([p], tmp_path / f"cm{rep}", "cm", steps=[("cast", "linear:f32"), ("merge-linear", True)]))
+        for i in range(2):
+            parts = [src[f"blk.{i}.attn_{x}.weight"] for x in "qkv"]
+            want = np.concatenate([O.dequantize(int(ty), data).view(np.uint8) for _, ty, _, data in parts])
+            assert got[f"blk.{i}.attn_qkv.weight"][0] == 0
+            assert np.array_equal(got[f"blk.{i}.attn_qkv.weight"][2], want), (rep, i)

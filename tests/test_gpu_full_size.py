@@ -7,7 +7,7 @@ import gc
 import numpy as np
 import pytest
 
-from util import same_bits, same_bits16, first_diff
+from util import same_bits, same_bits16, first_diff, plan_entries, with_adjacency
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,8 @@ def torch_cuda():
 
 
 @pytest.mark.parametrize("name,out", [
-    ("llama7b_q4_k_m", "f32"), ("llama7b_q4_k_m", "f16"), ("tinyllama_q4_k_m", "bf16"),
+    ("llama7b_q4_k_m", "f32"), ("llama7b_q4_k_m", "f16"),
+    ("tinyllama_q4_k_m", "f32"), ("tinyllama_q4_k_m", "f16"), ("tinyllama_q4_k_m", "bf16"),
     ("llama7b_q2_k", "f32"), ("llama7b_q3_k", "f32"), ("llama7b_q5_k", "f32"), ("llama7b_q6_k", "f32"),
     ("llama7b_q4_0", "f32"), ("llama7b_q8_0", "f32"), ("llama7b_iq4_nl", "f32"), ("llama7b_iq4_xs", "f32"),
     ("llama70b_q4_k_m_iq4nl", "f16"),
@@ -53,7 +54,13 @@ def test_every_element_against_oracle(torch_cuda, oracle, name, out):
         tensors.append((ty, src, dst_all[at:at + ne]))
         at += ne
     b = g.Batch(tensors, {"f32": GGmlType.F32, "f16": GGmlType.F16, "bf16": GGmlType.BF16}[out])
-    assert b.launches == len({int(ty) for ty, _, _ in tensors})          # one launch per block type
+    # one launch per block type through the tile table; where the single-tensor kernel of a (type, output) pair
+    # has a group start, runs of adjacent tensors with 64 Mi elements and more get launches of their own
+    # (util.plan_entries restates the rule; util.with_adjacency finds which of these allocations happen to be adjacent).
+    ntypes = len({int(ty) for ty, _, _ in tensors})
+    assert b.launches == plan_entries(with_adjacency(tensors), ob)
+    if ob == 4 and name != "llama7b_q8_0":
+        assert b.launches == ntypes
     b.run()
     t.cuda.synchronize()
     o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
@@ -85,6 +92,63 @@ def test_every_element_against_oracle(torch_cuda, oracle, name, out):
         assert (len(tensors), elems) == (226, 6_738_149_376)
     if name.startswith("llama70b"):
         assert elems == 68_975_329_280
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_one_rank_of_the_eight_gpu_70b_split(torch_cuda, oracle, rank):
+    """What ONE GPU of the 8-GPU run of the Llama-70B Q4_K_M + IQ4_NL set executes: its share of the index
+    partition (about 8.6 G elements, 5 GB packed, 34 GB of f32 output), decoded twice -- resident, through one
+    launch plan, every element against the oracle; then streamed from page-locked host memory through
+    ggq_dequantize_async into a second buffer, which must equal the first bit for bit."""
+    import gguf_amd as g
+    from gguf_amd import shard, synth
+    from gguf_amd.quants import GGmlType, block_bytes
+    t = torch_cuda
+    items = synth.workload("llama70b_q4_k_m_iq4nl")
+    shares = shard.partition(items, 8, out_bytes=4)
+    assert sum(p.elems for sh in shares for p in sh) == 68_975_329_280
+    mine = shares[rank]
+    elems = sum(p.elems for p in mine)
+    packed_bytes = sum(p.packed_bytes for p in mine)
+    assert 8.0e9 < elems < 9.3e9
+    gc.collect()
+    t.cuda.empty_cache()
+    if 2 * elems * 4 + packed_bytes + (4 << 30) > t.cuda.mem_get_info()[0]:
+        pytest.skip("not enough free HBM")
+    dst_all = t.empty(elems, dtype=t.float32, device="cuda")
+    dst_all.view(t.int32).fill_(0x7FC00001)
+    tensors, at = [], 0
+    for i, p in enumerate(mine):
+        src = synth.random_blocks_device(p.ggml_type, p.blocks, 0xC0FFEE05 + 1000 * rank + i, "cuda")
+        tensors.append((p.ggml_type, src, dst_all[at:at + p.elems]))
+        at += p.elems
+    b = g.Batch(tensors, GGmlType.F32)
+    b.run()
+    t.cuda.synchronize()
+    for (ty, src, dst), p in zip(tensors, mine):
+        want = oracle.dequantize(int(ty), src.cpu().numpy(), oracle.F32, threads=16).view(np.uint32)
+        got = dst.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (rank, p.name, p.block_begin, first_diff(got, want))
+    b.close()
+    # streamed: the same packed bytes from page-locked host memory, piece by piece, copy and decode overlapping
+    host = t.empty(packed_bytes, dtype=t.uint8, pin_memory=True)
+    again = t.empty(elems, dtype=t.float32, device="cuda")
+    again.view(t.int32).fill_(0x7FC00002)
+    work, at_b, at_e = [], 0, 0
+    for (ty, src, _), p in zip(tensors, mine):
+        n = p.blocks * block_bytes(ty)
+        host[at_b:at_b + n].copy_(src)
+        work.append((ty, again[at_e:at_e + p.elems], host[at_b:at_b + n]))
+        at_b += n
+        at_e += p.elems
+    t.cuda.synchronize()
+    ctx = g.Context(0, staging_bytes=128 << 20)
+    for ty, dst, h in work:
+        ctx.dequantize_async(ty, dst, h)
+    ctx.sync()
+    ctx.close()
+    assert t.equal(again.view(t.int32), dst_all.view(t.int32)), (rank, "streamed decode differs from the resident one")
+    del again, dst_all, host, tensors, work
 
 
 def test_tinyllama_f16_q8_0_round_trip_whole_model(torch_cuda, oracle):
