@@ -66,6 +66,7 @@ SYMBOLS = {
     "ggq_scale_device": (_int, [_u32, _vp, _vp, _sz, ctypes.c_double, _vp]),
     "ggq_permute_qk_device": (_int, [_u32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp, _vp]),
     "ggq_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
+    "ggq_quant_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
     "ggq_batch_run": (_int, [_vp, _vp]),
     "ggq_batch_launches": (_sz, [_vp]),
     "ggq_batch_destroy": (None, [_vp]),

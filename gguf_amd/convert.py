@@ -145,6 +145,19 @@ class Cast:
         return (isinstance(self.src, Borrowed) and self.to_ty in _FLOATS and self.from_ty not in (GGmlType.F32,)
                 and (self.from_ty not in _FLOATS or self.to_ty == GGmlType.F32) and block_bytes(self.from_ty) != 0)
 
+    def is_encode(self):
+        """A quantization (or narrowing) of float elements that come straight from an input file: the casts that
+        can share one quantize plan with others of their kind (quantize::<Blk, T, N>, cast.rs:140-148)."""
+        if not isinstance(self.src, Borrowed) or self.from_ty not in _FLOATS or self.to_ty not in _QUANTIZABLE:
+            return False
+        if self.to_ty == GGmlType.F32:
+            return False
+        if self.from_ty == self.to_ty or self.src.arr is None:
+            return False
+        n = self.src.arr.size // (4 if self.from_ty == GGmlType.F32 else 2)
+        be = block_elems(self.to_ty)
+        return n % self.row == 0 and self.row % be == 0        # the others raise Indivisible when evaluated alone
+
 
 class Concat:
     """concat(1, parts) (merge.rs:279-324): rows of the parts one after another."""
@@ -809,22 +822,31 @@ class _Producer:
         self._thread.start()
 
     def _units(self):
-        """File order, cut into units: a list of decode casts that share a plan, or one other tensor."""
-        units, run, held = [], [], 0
+        """File order, cut into units: ("decode", [casts that share a decode plan]), ("encode", [casts that share
+        a quantize plan]) or ("one", (name, tensor))."""
+        units, run, kind, held = [], [], None, 0
+
+        def close():
+            nonlocal run, kind, held
+            if run:
+                units.append((kind, run))
+            run, kind, held = [], None, 0
+
         for name, t in self._tensors:
-            if isinstance(t.data, Cast) and t.data.is_decode() and t.data.src.arr is not None:
-                if run and held + t.nbytes > self._group_bytes:
-                    units.append(run)
-                    run, held = [], 0
-                run.append((name, t))
-                held += t.nbytes
-            else:
-                if run:
-                    units.append(run)
-                    run, held = [], 0
-                units.append((name, t))
-        if run:
-            units.append(run)
+            k = None
+            if isinstance(t.data, Cast) and isinstance(t.data.src, Borrowed) and t.data.src.arr is not None:
+                k = "decode" if t.data.is_decode() else "encode" if t.data.is_encode() else None
+            if k is None:
+                close()
+                units.append(("one", (name, t)))
+                continue
+            size = max(t.nbytes, t.data.src.arr.size)
+            if run and (k != kind or held + size > self._group_bytes):
+                close()
+            kind = k
+            run.append((name, t))
+            held += size
+        close()
         return units
 
     def _emit(self, name, t, out, stream):
@@ -841,7 +863,7 @@ class _Producer:
 
     def _run(self):
         torch = self._torch
-        from .quants import Batch, Context
+        from .quants import Batch, Context, QuantBatch
         dev = f"cuda:{self._device}"
         ctx = None
         try:
@@ -861,8 +883,44 @@ class _Producer:
                     return d
 
                 with torch.cuda.stream(stream):
-                    for unit in self._units():
-                        if isinstance(unit, list):
+                    for kind, unit in self._units():
+                        if kind == "encode":
+                            # the same for quantizing casts: per (element type, target type) pair one element arena
+                            # and one packed arena, one quantize plan per element type
+                            pairs = {}
+                            for k, (name, t) in enumerate(unit):
+                                pairs.setdefault((int(t.data.from_ty), int(t.data.to_ty)), []).append(k)
+                            ctx.wait_stream(stream.cuda_stream)
+                            outs, by_in, keep = [None] * len(unit), {}, []
+                            for (from_ty, to_ty), members in pairs.items():
+                                eb = 4 if from_ty == GGmlType.F32 else 2
+                                nbytes = sum(unit[k][1].data.src.arr.size for k in members)
+                                nblocks = nbytes // eb // block_elems(to_ty)
+                                elems = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                                packed = torch.empty(nblocks * block_bytes(to_ty), dtype=torch.uint8, device=dev)
+                                keep += [elems, packed]
+                                at_e = at_b = 0
+                                for k in members:
+                                    arr = unit[k][1].data.src.arr
+                                    nb = arr.size // eb // block_elems(to_ty) * block_bytes(to_ty)
+                                    ctx.upload_async(elems[at_e:at_e + arr.size], arr)
+                                    outs[k] = packed[at_b:at_b + nb]
+                                    by_in.setdefault(from_ty, []).append(
+                                        (to_ty, elems[at_e:at_e + arr.size].view(_torch_dtype(GGmlType(from_ty))), outs[k]))
+                                    at_e += arr.size
+                                    at_b += nb
+                            plans = [QuantBatch(v, k) for k, v in by_in.items()]
+                            ctx.sync()
+                            for p in plans:
+                                p.run(stream.cuda_stream)
+                                self.launches += p.launches
+                            for (name, t), od in zip(unit, outs):
+                                if not self._emit(name, t, od, stream):
+                                    return
+                            for p in plans:
+                                p.close()
+                            del outs, by_in, keep
+                        elif kind == "decode":
                             # Typed layout: the unit's tensors of one (source type, output type) pair sit back to
                             # back in one packed arena and in one output arena, in file order, so that the launch
                             # plan sees one long run per pair (ggq_batch_create merges adjacent tensors).

@@ -340,6 +340,48 @@ ggq_status launch_quant_in(uint32_t ty, uint32_t in_ty, void *d_dst, const void 
     }
 }
 
+// Tile geometry of the quantizers on the host: the numbers of QuantGeom<Q, In>.
+#define GGQ_ENCODERS(XQ)                                                                                    \
+    XQ(GGQ_TYPE_Q4_0, EncQ4_0) XQ(GGQ_TYPE_Q4_1, EncQ4_1) XQ(GGQ_TYPE_Q5_0, EncQ5_0) XQ(GGQ_TYPE_Q5_1, EncQ5_1) \
+    XQ(GGQ_TYPE_Q8_0, EncQ8_0) XQ(GGQ_TYPE_Q8_1, EncQ8_1) XQ(GGQ_TYPE_Q8K, EncQ8K)
+
+template <class In>
+bool quant_geom(uint32_t ty, HostGeom &g) {
+    switch (ty) {
+#define XQ(ID, Q) case ID: g = {QuantGeom<Q, In>::ELEMS, QuantGeom<Q, In>::TB, QuantGeom<Q, In>::TBYTES}; return true;
+        GGQ_ENCODERS(XQ)
+#undef XQ
+    default: return false;
+    }
+}
+bool quant_geom_in(uint32_t ty, uint32_t in_ty, HostGeom &g) {
+    switch (in_ty) {
+    case GGQ_TYPE_F32: return quant_geom<InF32>(ty, g);
+    case GGQ_TYPE_F16: return quant_geom<InF16>(ty, g);
+    case GGQ_TYPE_BF16: return quant_geom<InBF16>(ty, g);
+    default: return false;
+    }
+}
+
+template <class In>
+ggq_status launch_quant_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hipStream_t st) {
+    switch (ty) {
+#define XQ(ID, Q)                                                                                        \
+    case ID:                                                                                             \
+        for (uint64_t t0 = 0; t0 < ntiles; t0 += kMaxGrid) {                                             \
+            uint64_t n = std::min(kMaxGrid, ntiles - t0);                                                \
+            hipLaunchKernelGGL((quant_batch<Q, In>), dim3((uint32_t)n), dim3(QuantGeom<Q, In>::THR), 0, st, d_table, t0); \
+        }                                                                                                \
+        break;
+        GGQ_ENCODERS(XQ)
+#undef XQ
+    default:
+        return GGQ_UNSUPPORTED;
+    }
+    HIP_TRY(hipGetLastError());
+    return GGQ_OK;
+}
+
 // ---- scaling ----------------------------------------------------------------------
 // The factor in the tensor's type, as the reference converts it (to_llama.rs:102-105).  f32 is `scale as f32`.
 // f16 is f16::from_f64 of the crate `half`, which on an x86 host with F16C narrows through f32 (two
@@ -439,7 +481,8 @@ ggq_status launch_batch(uint32_t ty, const TileRef *d_table, uint64_t ntiles, hi
 struct ggq_batch {
     int device = 0;
     int cus = 0;
-    uint32_t out_ty = 0;
+    uint32_t out_ty = 0;          // decode plans: the output element type; quantize plans: the INPUT element type
+    bool quantize = false;        // a plan made by ggq_quant_batch_create: elements -> packed blocks
     struct Group {
         uint32_t ty;
         uint64_t first, ntiles;   // first record in the device tile table (a multiple of 64), tiles in the group
@@ -661,6 +704,63 @@ void pool_put(ggq_ctx *c) {
     (*g_pool)[c->device].push_back(c);
 }
 
+}  // namespace
+
+namespace {
+// Builds the device tile table of a plan from its runs: one TileRef per tile, the runs of one type consecutive
+// (caller's order inside a type).  The host only writes one descriptor per run; a small kernel per group expands
+// them.  geom(ty) gives the tile geometry; tile_in / tile_out = bytes a whole tile reads / writes.
+struct PlanRun { uint32_t ty; uint64_t src, dst, blocks; };
+template <class GeomOf>
+ggq_status build_plan_table(ggq_batch *b, const std::vector<PlanRun> &runs, const std::vector<uint32_t> &types,
+                            bool per_xcd, GeomOf geom) {
+    std::vector<TensorDesc> descs;
+    struct Span { size_t desc0, ndesc; };
+    std::vector<Span> spans;
+    uint64_t total_tiles = 0;
+    for (uint32_t ty : types) {
+        uint64_t tile_blocks, tile_in, tile_out;
+        geom(ty, tile_blocks, tile_in, tile_out);
+        ggq_batch::Group g{ty, total_tiles, 0};
+        Span sp{descs.size(), 0};
+        for (const PlanRun &r : runs) {
+            if (r.ty != ty) continue;
+            if (r.src >> 48) return GGQ_INVALID;
+            descs.push_back({r.src, r.dst, r.blocks, g.ntiles});
+            g.ntiles += (r.blocks + tile_blocks - 1) / tile_blocks;
+            ++sp.ndesc;
+        }
+        total_tiles += (g.ntiles + 63) / 64 * 64;      // record_slot() permutes within runs of 64
+        b->groups.push_back(g);
+        spans.push_back(sp);
+    }
+    if (total_tiles == 0) return GGQ_OK;
+    TensorDesc *d_desc = nullptr;
+    bool ok = hip_ok(hipMalloc((void **)&b->d_table, total_tiles * sizeof(TileRef)), "hipMalloc") &&
+              hip_ok(hipMalloc((void **)&d_desc, descs.size() * sizeof(TensorDesc)), "hipMalloc") &&
+              hip_ok(hipMemcpy(d_desc, descs.data(), descs.size() * sizeof(TensorDesc), hipMemcpyHostToDevice), "hipMemcpy");
+    for (size_t k = 0; ok && k < b->groups.size(); ++k) {
+        const auto &g = b->groups[k];
+        uint64_t tile_blocks, tile_in, tile_out;
+        geom(g.ty, tile_blocks, tile_in, tile_out);
+        for (uint64_t t0 = 0; t0 < g.ntiles; t0 += kMaxGrid * 256) {
+            const uint64_t end = std::min(g.ntiles, t0 + kMaxGrid * 256);
+            const dim3 grid((uint32_t)((end - t0 + 255) / 256)), wg(256);
+            if (per_xcd)
+                hipLaunchKernelGGL(build_tile_table<true>, grid, wg, 0, (hipStream_t)0, b->d_table + g.first,
+                                   d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end, (uint32_t)tile_blocks,
+                                   (uint32_t)tile_in, (uint32_t)tile_out);
+            else
+                hipLaunchKernelGGL(build_tile_table<false>, grid, wg, 0, (hipStream_t)0, b->d_table + g.first,
+                                   d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end, (uint32_t)tile_blocks,
+                                   (uint32_t)tile_in, (uint32_t)tile_out);
+        }
+        ok = hip_ok(hipGetLastError(), "build_tile_table");
+    }
+    ok = ok && hip_ok(hipStreamSynchronize((hipStream_t)0), "hipStreamSynchronize");
+    if (d_desc) (void)hipFree(d_desc);
+    return ok ? GGQ_OK : GGQ_DEVICE;
+}
 }  // namespace
 
 // ---- per-device state of ggq_dequantize_noalloc ------------------------------------
@@ -1034,12 +1134,11 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
     // Route every tensor (the rule is stated at kHybridMinElems).  F16 / BF16 sources are widened one launch each.
     // Block types: adjacent tensors are merged into runs; a run goes to a launch of its own or, as ONE entry, into
     // the tile table of its type.
-    struct Run { uint32_t ty; uint64_t src, dst, blocks; };
-    std::vector<Run> runs;                 // table entries, in the caller's order
+    std::vector<PlanRun> runs;             // table entries, in the caller's order
     std::vector<uint32_t> types;
     {
         const uint64_t ob = out_bytes(out_ty);
-        std::vector<Run> merged;
+        std::vector<PlanRun> merged;
         for (size_t i = 0; i < count; ++i) {
             const uint32_t ty = tensors[i].ggml_type;
             if (tensors[i].blocks == 0) continue;
@@ -1050,7 +1149,7 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
             const TypeInfo *ti = type_info(ty);
             const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
             // the run of this type that was extended last, if this tensor continues it
-            Run *prev = nullptr;
+            PlanRun *prev = nullptr;
             for (size_t k = merged.size(); k-- > 0;)
                 if (merged[k].ty == ty) { prev = &merged[k]; break; }
             if (prev && prev->src + prev->blocks * ti->bytes == src && prev->dst + prev->blocks * ti->elems * ob == dst)
@@ -1058,7 +1157,7 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
             else
                 merged.push_back({ty, src, dst, tensors[i].blocks});
         }
-        for (const Run &r : merged) {
+        for (const PlanRun &r : merged) {
             const uint64_t elems = r.blocks * type_info(r.ty)->elems;
             if (elems >= kHybridMinElems && (kHybridAny || pick_prefetch(r.ty, out_ty, false, elems).wait != 0)) {
                 b->single.push_back({r.ty, (const void *)(uintptr_t)r.src, (void *)(uintptr_t)r.dst, r.blocks});
@@ -1068,58 +1167,78 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
             if (std::find(types.begin(), types.end(), r.ty) == types.end()) types.push_back(r.ty);
         }
     }
-    // One TileRef per tile, tensors of one type consecutive (caller's order inside a type).  The host only
-    // writes one descriptor per tensor; a small kernel per group expands them into the table.
-    std::vector<TensorDesc> descs;
-    struct Span { size_t desc0, ndesc; };
-    std::vector<Span> spans;
-    const uint64_t ob = out_bytes(out_ty);
-    uint64_t total_tiles = 0;
-    for (uint32_t ty : types) {
-        const TypeInfo *ti = type_info(ty);
-        const HostGeom hg = host_geom(ti, out_ty);
-        ggq_batch::Group g{ty, total_tiles, 0};
-        Span sp{descs.size(), 0};
-        for (const Run &r : runs) {
-            if (r.ty != ty) continue;
-            if (r.src >> 48) { ggq_batch_destroy(b); return GGQ_INVALID; }
-            descs.push_back({r.src, r.dst, r.blocks, g.ntiles});
-            g.ntiles += (r.blocks + hg.blocks - 1) / hg.blocks;
-            ++sp.ndesc;
-        }
-        total_tiles += (g.ntiles + 63) / 64 * 64;      // record_slot() permutes within runs of 64
-        b->groups.push_back(g);
-        spans.push_back(sp);
+    const bool per_xcd = out_ty == GGQ_TYPE_F32 ? RecordOrder<OutF32>::PER_XCD : RecordOrder<OutF16>::PER_XCD;
+    st = build_plan_table(b, runs, types, per_xcd, [&](uint32_t ty, uint64_t &tb, uint64_t &tin, uint64_t &tout) {
+        const HostGeom hg = host_geom(type_info(ty), out_ty);
+        tb = hg.blocks;
+        tin = hg.bytes;
+        tout = hg.elems * out_bytes(out_ty);
+    });
+    if (st != GGQ_OK) {
+        ggq_batch_destroy(b);
+        return st;
     }
-    if (total_tiles) {
-        TensorDesc *d_desc = nullptr;
-        bool ok = hip_ok(hipMalloc((void **)&b->d_table, total_tiles * sizeof(TileRef)), "hipMalloc") &&
-                  hip_ok(hipMalloc((void **)&d_desc, descs.size() * sizeof(TensorDesc)), "hipMalloc") &&
-                  hip_ok(hipMemcpy(d_desc, descs.data(), descs.size() * sizeof(TensorDesc), hipMemcpyHostToDevice),
-                         "hipMemcpy");
-        for (size_t k = 0; ok && k < b->groups.size(); ++k) {
-            const auto &g = b->groups[k];
-            const HostGeom hg = host_geom(type_info(g.ty), out_ty);
-            for (uint64_t t0 = 0; t0 < g.ntiles; t0 += kMaxGrid * 256) {
-                const uint64_t end = std::min(g.ntiles, t0 + kMaxGrid * 256);
-                const dim3 grid((uint32_t)((end - t0 + 255) / 256)), wg(256);
-                if (out_ty == GGQ_TYPE_F32)
-                    hipLaunchKernelGGL(build_tile_table<RecordOrder<OutF32>::PER_XCD>, grid, wg, 0, (hipStream_t)0,
-                                       b->d_table + g.first, d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end,
-                                       (uint32_t)hg.blocks, (uint32_t)hg.bytes, (uint32_t)(hg.elems * ob));
-                else
-                    hipLaunchKernelGGL(build_tile_table<RecordOrder<OutF16>::PER_XCD>, grid, wg, 0, (hipStream_t)0,
-                                       b->d_table + g.first, d_desc + spans[k].desc0, (uint32_t)spans[k].ndesc, t0, end,
-                                       (uint32_t)hg.blocks, (uint32_t)hg.bytes, (uint32_t)(hg.elems * ob));
-            }
-            ok = hip_ok(hipGetLastError(), "build_tile_table");
+    *out = b;
+    return GGQ_OK;
+}
+
+ggq_status ggq_quant_batch_create(const ggq_tensor *tensors, size_t count, uint32_t in_ty, ggq_batch **out) {
+    if (!out || (count && !tensors)) return GGQ_INVALID;
+    const uint64_t ib = out_bytes(in_ty);
+    if (ib == 0) return GGQ_UNSUPPORTED;
+    for (size_t i = 0; i < count; ++i) {
+        if (!type_info(tensors[i].ggml_type) || !can_quantize(tensors[i].ggml_type)) return GGQ_UNSUPPORTED;
+        if (tensors[i].blocks && (!tensors[i].d_src || !tensors[i].d_dst)) return GGQ_INVALID;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DevInfo di;
+    ggq_status st = dev_info(dev, di);
+    if (st != GGQ_OK) return st;
+    // Tensors of one target type that are adjacent in memory (elements and packed blocks) are one run; F16 / BF16
+    // targets are narrowed one launch per run, block types share one launch per type.
+    std::vector<PlanRun> merged, runs;
+    std::vector<uint32_t> types;
+    for (size_t i = 0; i < count; ++i) {
+        const uint32_t ty = tensors[i].ggml_type;
+        if (tensors[i].blocks == 0) continue;
+        const TypeInfo *ti = type_info(ty);
+        const uint64_t src = (uint64_t)(uintptr_t)tensors[i].d_src, dst = (uint64_t)(uintptr_t)tensors[i].d_dst;
+        PlanRun *prev = nullptr;
+        for (size_t k = merged.size(); k-- > 0;)
+            if (merged[k].ty == ty) { prev = &merged[k]; break; }
+        if (prev && prev->src + prev->blocks * ti->elems * ib == src && prev->dst + prev->blocks * ti->bytes == dst)
+            prev->blocks += tensors[i].blocks;
+        else
+            merged.push_back({ty, src, dst, tensors[i].blocks});
+    }
+    // alignment is a property of a run's start: the tiles of a run are cut from there
+    for (const PlanRun &r : merged)
+        if (r.src % 16 != 0 || r.dst % 16 != 0) return GGQ_MISALIGNED;
+    ggq_batch *b = new (std::nothrow) ggq_batch();
+    if (!b) return GGQ_INVALID;
+    b->device = dev;
+    b->cus = di.cus;
+    b->out_ty = in_ty;
+    b->quantize = true;
+    for (const PlanRun &r : merged) {
+        if (r.ty == GGQ_TYPE_F16 || r.ty == GGQ_TYPE_BF16) {
+            b->plain.push_back({r.ty, (const void *)(uintptr_t)r.src, (void *)(uintptr_t)r.dst, r.blocks});
+            continue;
         }
-        ok = ok && hip_ok(hipStreamSynchronize((hipStream_t)0), "hipStreamSynchronize");
-        if (d_desc) (void)hipFree(d_desc);
-        if (!ok) {
-            ggq_batch_destroy(b);
-            return GGQ_DEVICE;
-        }
+        runs.push_back(r);
+        if (std::find(types.begin(), types.end(), r.ty) == types.end()) types.push_back(r.ty);
+    }
+    st = build_plan_table(b, runs, types, false, [&](uint32_t ty, uint64_t &tb, uint64_t &tin, uint64_t &tout) {
+        HostGeom g{};
+        (void)quant_geom_in(ty, in_ty, g);
+        tb = g.blocks;
+        tin = g.elems * ib;
+        tout = g.bytes;
+    });
+    if (st != GGQ_OK) {
+        ggq_batch_destroy(b);
+        return st;
     }
     *out = b;
     return GGQ_OK;
@@ -1135,6 +1254,23 @@ ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
         return GGQ_INVALID;
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    if (b->quantize) {
+        for (const auto &g : b->groups) {
+            ggq_status rc;
+            const TileRef *tab = b->d_table + g.first;
+            switch (b->out_ty) {
+            case GGQ_TYPE_F32: rc = launch_quant_batch<InF32>(g.ty, tab, g.ntiles, st); break;
+            case GGQ_TYPE_F16: rc = launch_quant_batch<InF16>(g.ty, tab, g.ntiles, st); break;
+            default: rc = launch_quant_batch<InBF16>(g.ty, tab, g.ntiles, st); break;
+            }
+            if (rc != GGQ_OK) return rc;
+        }
+        for (const auto &p : b->plain) {      // F16 / BF16 targets: p.src = elements, p.dst = narrowed elements
+            ggq_status rc = launch_quant_in(p.ty, b->out_ty, p.dst, p.src, p.n, b->cus, st);
+            if (rc != GGQ_OK) return rc;
+        }
+        return GGQ_OK;
+    }
     for (const auto &g : b->groups) {
         ggq_status rc;
         const TileRef *tab = b->d_table + g.first;

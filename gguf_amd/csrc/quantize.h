@@ -423,19 +423,14 @@ struct QuantGeom {
     static_assert(TBYTES % 16 == 0, "tiles leave as whole 16-byte stores");
 };
 
-// src: elements (16-byte aligned), dst: packed blocks (16-byte aligned), workgroup b -> tile b
-template <class Q, class In, bool NTL = true, bool NTS = true>
-__global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const typename In::T *__restrict__ src,
-                                                                    uint8_t *__restrict__ dst, uint64_t nblocks) {
+// One tile: `in` = the tile's first element (16-byte aligned), `out` = its first packed block (16-byte aligned),
+// nblk blocks present (<= TB).
+template <class Q, class In, bool NTL, bool NTS>
+__device__ __forceinline__ void quant_tile(uint8_t *lds, const typename In::T *in, uint8_t *out, uint32_t nblk) {
     typedef QuantGeom<Q, In> G;
     constexpr uint32_t THR = G::THR, LPT = G::LPT;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[G::TBYTES];
     const uint32_t tid = threadIdx.x;
-    const uint64_t t = blockIdx.x;
-    const uint64_t rem = nblocks - t * G::TB;
-    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
     constexpr uint32_t LANES = Q::N / In::EPL;          // lanes per block
-    const typename In::T *in = src + t * G::ELEMS;
     float x[LPT][In::EPL];
 #pragma unroll
     for (uint32_t i = 0; i < LPT; ++i) {
@@ -453,7 +448,6 @@ __global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const type
     __syncthreads();
     // packed tile -> global, 16 bytes per thread per pass; a short last tile ends in a byte tail
     const uint32_t nbytes = nblk * Q::BYTES;
-    uint8_t *out = dst + t * G::TBYTES;
     for (uint32_t o = tid * 16; o + 16 <= nbytes; o += THR * 16) {
         const uint4v v = *(const uint4v *)(lds + o);
         if (NTS) __builtin_nontemporal_store(v, (uint4v *)(out + o));
@@ -461,6 +455,31 @@ __global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const type
     }
     const uint32_t tail0 = nbytes & ~15u;
     if (tail0 + tid < nbytes) out[tail0 + tid] = lds[tail0 + tid];
+}
+
+// One tensor per launch.  src: elements (16-byte aligned), dst: packed blocks (16-byte aligned), workgroup b -> tile b
+template <class Q, class In, bool NTL = true, bool NTS = true>
+__global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_one(const typename In::T *__restrict__ src,
+                                                                    uint8_t *__restrict__ dst, uint64_t nblocks) {
+    typedef QuantGeom<Q, In> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::TBYTES];
+    const uint64_t t = blockIdx.x;
+    const uint64_t rem = nblocks - t * G::TB;
+    const uint32_t nblk = rem < G::TB ? (uint32_t)rem : G::TB;
+    quant_tile<Q, In, NTL, NTS>(lds, src + t * G::ELEMS, dst + t * G::TBYTES, nblk);
+}
+
+// Many tensors per launch (the quantizing counterpart of deq_batch): workgroup b encodes tile tile0 + b of the
+// group; its record (same TileRef as the decode plans, in tile order) holds the address of the tile's first
+// ELEMENT with the tile's block count in the top 16 bits, and the address of its first packed block.  Without it a
+// model's tensors cost one launch each, and below some 8 M elements a launch is mostly ramp and drain.
+template <class Q, class In>
+__global__ __launch_bounds__((QuantShape<Q, In>::THR)) void quant_batch(const TileRef *__restrict__ table, uint64_t tile0) {
+    typedef QuantGeom<Q, In> G;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[G::TBYTES];
+    const TileRef me = table[tile0 + blockIdx.x];
+    quant_tile<Q, In, true, true>(lds, (const typename In::T *)(me.src_nblk & 0xFFFFFFFFFFFFull), (uint8_t *)me.dst,
+                                  (uint32_t)(me.src_nblk >> 48));
 }
 
 // ---- f32 / f16 / bf16 -> f16 / bf16 (the 1-element "blocks", half.rs:10-17, 26-33) ----

@@ -308,6 +308,38 @@ class Batch:
             pass
 
 
+class QuantBatch(Batch):
+    """A launch plan that QUANTIZES many device-resident tensors (ggq_quant_batch_create): one kernel launch per
+    target block type instead of one per tensor -- the loop over tensors of the reference's cast operator
+    (xtask/src/utils/operator/cast.rs:73-90) when its iterations end in quantize_slice (cast.rs:140-148)."""
+
+    def __init__(self, tensors, in_ty=None):
+        """tensors: iterable of (target ggml_type, src cuda tensor of elements, dst uint8 cuda tensor); all sources
+        share one element type (float32, float16 or bfloat16), which `in_ty` names when the table is empty."""
+        tensors = list(tensors)
+        self._keep = tensors
+        arr = (_lib.ggq_tensor * max(1, len(tensors)))()
+        for i, (ty, src, dst) in enumerate(tensors):
+            bb, be = block_bytes(ty), block_elems(ty)
+            if bb == 0:
+                raise Unsupported()
+            this_in = _out_type(src)
+            if in_ty is None:
+                in_ty = this_in
+            if int(this_in) != int(in_ty):
+                raise ValueError("all sources of one quantize plan must have the same element type")
+            nbytes = dst.numel() * dst.element_size()
+            if src.numel() % be:
+                raise Indivisible()
+            if nbytes % bb or nbytes // bb != src.numel() // be:
+                raise LengthMismatch()
+            arr[i] = _lib.ggq_tensor(int(ty), 0, src.data_ptr(), dst.data_ptr(), nbytes // bb)
+        h = ctypes.c_void_p()
+        check(lib.ggq_quant_batch_create(arr, len(tensors), int(in_ty if in_ty is not None else GGmlType.F32),
+                                         ctypes.byref(h)))
+        self._h = h
+
+
 class Context:
     """Streamed host -> device decode on one GPU (ggq_ctx_*)."""
 

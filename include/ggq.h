@@ -181,6 +181,17 @@ typedef struct ggq_batch ggq_batch;
  * device table).  The plan can be run any number of times. */
 ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t out_type,
                             ggq_batch **out);
+/* The same for the other direction: a plan that QUANTIZES many device-resident tensors with one kernel launch per
+ * target block type -- the reference's loop over tensors when its iterations end in quantize_slice
+ * (xtask/src/utils/operator/cast.rs:140-148 -> ggml-quants/src/lib.rs:121-133).  In each entry d_src points at
+ * `blocks * ggq_block_elems(ggml_type)` ELEMENTS of type `in_type` (F32, F16 or BF16, the same for the whole plan)
+ * and d_dst receives `blocks` packed blocks; both 16-byte aligned (GGQ_MISALIGNED), except that a tensor whose
+ * elements and blocks start exactly where those of the previous tensor of its type end continues that tensor's run
+ * and needs no alignment of its own.  Target types: those
+ * ggq_quantize_device encodes (others: GGQ_UNSUPPORTED); F16 / BF16 targets are narrowed with one launch per run of
+ * adjacent tensors.  The plan is run, counted and destroyed with ggq_batch_run / _launches / _destroy. */
+ggq_status ggq_quant_batch_create(const ggq_tensor *tensors, size_t count, uint32_t in_type,
+                                  ggq_batch **out);
 /* Enqueues the plan's kernels on `hip_stream`; does not synchronize.  The device that was
  * current at ggq_batch_create must be current again (GGQ_INVALID otherwise). */
 ggq_status ggq_batch_run(ggq_batch *batch, void *hip_stream);

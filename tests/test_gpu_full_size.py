@@ -188,3 +188,40 @@ def test_tinyllama_f16_q8_0_round_trip_whole_model(torch_cuda, oracle):
         del w16, q, y
     assert total == 1_099_956_224
     assert worst < 4.5e-3
+
+
+def test_tinyllama_f16_to_q8_0_one_plan_every_byte(torch_cuda, oracle):
+    """The first benchmark configuration's quantizing half at full size through ONE quantize plan
+    (ggq_quant_batch_*): the 90 two-dimensional F16 tensors of the TinyLlama table (1.1 G elements, seeded payload)
+    to Q8_0 with a single kernel launch, every packed byte against the oracle's quantizer."""
+    import json
+    import os
+    import gguf_amd as g
+    t = torch_cuda
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tinyllama_table.json")))["tensors"]
+    mats = [x for x in table if x["type"] == 1 and len(x["shape"]) == 2]
+    assert len(mats) == 90
+    gen = t.Generator(device="cuda")
+    gen.manual_seed(0xC0FFEE01)
+    tensors = []
+    for x in mats:
+        n = x["shape"][0] * x["shape"][1]
+        w16 = (t.randn(n, device="cuda", generator=gen) * 0.02).to(t.float16)
+        tensors.append((8, w16, t.empty(n // 32 * 34, dtype=t.uint8, device="cuda")))
+    b = g.QuantBatch(tensors)
+    assert b.launches == 1
+    b.run()
+    t.cuda.synchronize()
+    from concurrent.futures import ThreadPoolExecutor
+
+    def same(k):                # the oracle's quantizer is single-threaded; ctypes releases the interpreter lock
+        _, w16, q = tensors[k]
+        want = oracle.quantize(8, w16.view(t.int16).cpu().numpy().view(np.uint16), in_ty=oracle.F16)
+        return np.array_equal(q.cpu().numpy(), want)
+
+    with ThreadPoolExecutor(8) as pool:
+        for x, ok in zip(mats, pool.map(same, range(len(tensors)))):
+            assert ok, x["name"]
+    total = sum(w16.numel() for _, w16, _ in tensors)
+    b.close()
+    assert total == 1_099_956_224

@@ -211,3 +211,69 @@ def test_large_tensor_every_block(torch_cuda, oracle, ty, kind):
     if not np.array_equal(got, want):
         bad = np.nonzero(got != want)[0]
         raise AssertionError(f"type {ty} from {kind}: {bad.size} bytes differ, first at {int(bad[0])}")
+
+
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_quantize_plan_mixed(torch_cuda, oracle, kind):
+    """ggq_quant_batch_*: many tensors, every encoder plus the F16 / BF16 narrowing, in one plan: whole tiles, short
+    last tiles, single blocks, empty tensors, and tensors that follow each other in memory (one run).  Every packed
+    byte against the oracle; nothing written past a tensor's end."""
+    import gguf_amd as g
+    t = torch_cuda
+    rng = np.random.default_rng(77)
+    dt = {"f32": t.float32, "f16": t.float16, "bf16": t.bfloat16}[kind]
+    tile = 4096 if kind == "f32" else 8192
+    spec = [(8, 3 * tile + 32), (2, tile), (2, 32), (8, 0), (3, 5 * tile - 64), (6, 2 * tile + 96), (7, 64), (9, tile + 32),
+            (15, 256 * 37), (1, 1000), (30, 8 * 513), (8, 32 * 1001), (15, 256), (2, 7 * tile + 32 * 5), (1, 24), (9, 32)]
+    tensors, inputs = [], []
+    for i, (ty, n) in enumerate(spec):
+        x = (rng.standard_normal(n) * (0.02 if i % 3 else 3.0)).astype(np.float32)
+        if n >= 64:
+            x[5] = 0.0
+            x[33:40] = x[32]          # ties
+        arr = to_in(oracle, x, kind)
+        src = t.from_numpy(arr).cuda() if kind == "f32" else t.from_numpy(arr.view(np.int16)).cuda().view(dt)
+        nb = n // g.block_elems(ty) * g.block_bytes(ty)
+        dst = t.full((nb + 16,), 0xAB, dtype=t.uint8, device="cuda")
+        tensors.append((ty, src, dst[:nb]))
+        inputs.append((arr, dst))
+    # two tensors of one type back to back in one element buffer and one packed buffer: a single run
+    xa = (rng.standard_normal(32 * 300) * 0.5).astype(np.float32)
+    run_arr = to_in(oracle, xa, kind)
+    both = t.from_numpy(run_arr).cuda() if kind == "f32" else t.from_numpy(run_arr.view(np.int16)).cuda().view(dt)
+    packed = t.full((300 * 34 + 16,), 0xAB, dtype=t.uint8, device="cuda")
+    tensors += [(8, both[:32 * 100], packed[:100 * 34]), (8, both[32 * 100:], packed[100 * 34:300 * 34])]
+    b = g.QuantBatch(tensors)
+    # one launch per block type in the plan, one per run of F16 / BF16 targets
+    assert b.launches == len({ty for ty, n in spec if n and ty not in (1, 30)}) + sum(1 for ty, n in spec if ty in (1, 30))
+    for _ in range(2):
+        b.run()
+    t.cuda.synchronize()
+    for (ty, n), (arr, dst) in zip(spec, inputs):
+        nb = n // g.block_elems(ty) * g.block_bytes(ty)
+        out = dst.cpu().numpy()
+        assert (out[nb:] == 0xAB).all(), ("wrote past the end", ty, n)
+        check(oracle, ty, out[:nb], arr, kind)
+    out = packed.cpu().numpy()
+    assert (out[300 * 34:] == 0xAB).all()
+    check(oracle, 8, out[:300 * 34], run_arr, kind)
+    b.close()
+
+
+def test_quantize_plan_errors(torch_cuda):
+    import gguf_amd as g
+    t = torch_cuda
+    x = t.zeros(256, device="cuda")
+    q = t.zeros(144, dtype=t.uint8, device="cuda")
+    with pytest.raises(g.Unsupported):
+        g.QuantBatch([(12, x, q)])                                   # Q4_K has no quantizer in the reference
+    with pytest.raises(g.LengthMismatch):
+        g.QuantBatch([(8, x, t.zeros(34 * 7, dtype=t.uint8, device="cuda"))])
+    with pytest.raises(g.Indivisible):
+        g.QuantBatch([(8, x[:31], t.zeros(34, dtype=t.uint8, device="cuda"))])
+    with pytest.raises(g.Misaligned):
+        g.QuantBatch([(8, x[1:33], t.zeros(34, dtype=t.uint8, device="cuda"))])
+    with pytest.raises(ValueError):
+        g.QuantBatch([(8, x, t.zeros(34 * 8, dtype=t.uint8, device="cuda")),
+                      (8, x.half(), t.zeros(34 * 8, dtype=t.uint8, device="cuda"))])
+    g.QuantBatch([], g.GGmlType.F32).close()                          # an empty plan is fine
