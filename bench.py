@@ -591,6 +591,14 @@ def main():
     dom_elems_by_type = {ty: sum(x[2].numel() for x in share.by_type[ty]) for ty in share.order}
     launches = share.launches
     plan_launches = [b.launches for _, b in share.plans]
+    dom_name = GGmlType(share.order[0]).name
+    dom_table, dom_all = share.plans[0][1].table_launches, share.plans[0][1].launches
+    if dom_all == 1:
+        dom_kernel = (f"deq_batch<{dom_name},{args.out}>" if dom_table else
+                      f"deq_one<{dom_name},{args.out}> over the type's tensors as one run") + " (rank 0)"
+    else:
+        dom_kernel = (f"the {dom_name} -> {args.out} launch plan (rank 0): {dom_table} deq_batch launch over the tile table + "
+                      f"{dom_all - dom_table} deq_one launches for runs of 64 Mi elements and more")
 
     # secondary: weak scaling (every rank one whole set), when the headline is strong scaling
     weak = None
@@ -629,7 +637,7 @@ def main():
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
-                key = f"{args.workload}:{args.out}:{GGmlType(dom_ty).name}"
+                key = f"{args.workload}:{args.out}:{'' if typed else 'scattered:'}{GGmlType(dom_ty).name}"
                 if key in tr and world == 1:
                     traffic = tr[key].get("hbm_bytes_per_launch")
                     traffic_source = ("static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch recorded in "
@@ -663,10 +671,7 @@ def main():
             "algorithmic_GBps": round((pin + pout) / per / 1e9, 2),
             "kernels": [{"type": GGmlType(ty).name, "elements": dom_elems_by_type[ty], "launches": plan_launches[k],
                          "avg_ms": round(kern_ms[k], 4)} for k, ty in enumerate(order)],
-            "roofline": {"bound": "hbm",
-                         "kernel": f"deq_batch<{GGmlType(dom_ty).name},{args.out}> (rank 0)" if plan_launches[0] == 1 else
-                                   f"the {GGmlType(dom_ty).name} -> {args.out} launch plan (rank 0): deq_batch over the tile "
-                                   f"table + {plan_launches[0] - 1} deq_one launches for tensors of 64 Mi elements and more",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,

@@ -69,6 +69,7 @@ SYMBOLS = {
     "ggq_quant_batch_create": (_int, [ctypes.POINTER(ggq_tensor), _sz, _u32, ctypes.POINTER(_vp)]),
     "ggq_batch_run": (_int, [_vp, _vp]),
     "ggq_batch_launches": (_sz, [_vp]),
+    "ggq_batch_table_launches": (_sz, [_vp]),
     "ggq_batch_destroy": (None, [_vp]),
     "ggq_ctx_create": (_int, [_int, _sz, ctypes.POINTER(_vp)]),
     "ggq_dequantize_async": (_int, [_vp, _u32, _u32, _vp, _sz, _vp, _sz]),

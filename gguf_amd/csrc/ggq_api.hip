@@ -1292,6 +1292,8 @@ ggq_status ggq_batch_run(ggq_batch *b, void *hip_stream) {
     return GGQ_OK;
 }
 
+size_t ggq_batch_table_launches(const ggq_batch *b) { return b ? b->groups.size() : 0; }
+
 size_t ggq_batch_launches(const ggq_batch *b) {
     return b ? b->groups.size() + b->single.size() + b->plain.size() : 0;
 }

@@ -284,6 +284,11 @@ class Batch:
     def launches(self):
         return lib.ggq_batch_launches(self._h)
 
+    @property
+    def table_launches(self):
+        """How many of the launches go through a tile table (the others are runs with a launch of their own)."""
+        return lib.ggq_batch_table_launches(self._h)
+
     def run(self, stream=None):
         if stream is None:
             import torch

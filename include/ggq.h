@@ -197,6 +197,9 @@ ggq_status ggq_quant_batch_create(const ggq_tensor *tensors, size_t count, uint3
 ggq_status ggq_batch_run(ggq_batch *batch, void *hip_stream);
 /* Kernel launches one run issues (for measurement bookkeeping). */
 size_t ggq_batch_launches(const ggq_batch *batch);
+/* ... and how many of them go through a tile table (one per block type that has tensors in the table); the rest
+ * are runs with a launch of their own and F16 / BF16 tensors. */
+size_t ggq_batch_table_launches(const ggq_batch *batch);
 void ggq_batch_destroy(ggq_batch *batch);
 
 /* ---- streamed host -> device decode ---------------------------------------

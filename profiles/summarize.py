@@ -73,6 +73,10 @@ def main():
         fmt = k.split("<ggq::")[1].split(",")[0]
         read_b = 2.0 * fe[k] * 1024.0
         write_b = wr.get(k, 0.0) * 1024.0
+        # a plan can hold a table launch and single-tensor launches of one format: the entry is the larger launch
+        old = doc.get(f"{key}:{fmt}")
+        if old and old.get("round") == tag and old.get("kernel") != k and old["hbm_bytes_per_launch"] > read_b + write_b:
+            continue
         doc[f"{key}:{fmt}"] = {
             "kernel": k, "round": tag,
             "FETCH_SIZE_KiB_raw": fe[k], "WRITE_SIZE_KiB_raw": wr.get(k),

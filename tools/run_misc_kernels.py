@@ -16,7 +16,7 @@ from gguf_amd.quants import GGmlType as T  # noqa: E402
 import time  # noqa: E402
 
 n = 1 << 30
-reps = 30
+reps = 60          # the summary also prices the second half alone (the first launches after a change of load run slow)
 x = torch.randn(n, device="cuda") * 0.02
 bytes_per_launch = {}
 # the GPU reaches its steady clocks only after tens of milliseconds of load: keep it busy first
