@@ -148,6 +148,13 @@ struct Prefetch {
 // The address is wave-uniform, so the compiler issues the load through the scalar cache, and that is part of the
 // effect: the same probe forced onto the vector path (measured) turns the gain into a loss of 10-18 points.  The
 // description above is therefore a model that fits the measurements, not an established mechanism.
+// Cache assumption: the probe brings a line of the destination into the scalar cache, and this same kernel then
+// overwrites that line with vector stores, which the scalar cache does not see.  Nothing in this library reads a
+// decoded tensor through the scalar cache within the same kernel, and a LATER kernel that does (this kernel's own
+// probe on the next launch into the same buffer, or a consumer with wave-uniform loads) is safe because every kernel
+// dispatch on this runtime starts with an acquire that invalidates the scalar and vector L1 caches -- also between
+// the nodes of a replayed graph and between back-to-back launches in one stream.  The probed value itself is never
+// used, so a stale line could at worst be seen by a consumer, never by the decode.
 __device__ __forceinline__ uint32_t group_wait(const void *group_dst) {
     // the address is named as global memory (address space 1) outright: a pointer of unknown address space -- one
     // assembled from integers, as in deq_seg -- would be loaded with a flat (vector) instruction

@@ -48,9 +48,10 @@ struct ScaleOp {
     }
 };
 
-// dst[i] = src[i] * factor over 16-byte pieces; dst may be src.  `first`: piece this launch starts at.
+// dst[i] = src[i] * factor over 16-byte pieces; dst may be src (hence no __restrict__ on either).  `first`: piece
+// this launch starts at.
 template <uint32_t K>
-__global__ __launch_bounds__(STREAM_THREADS) void scale_vec(uint4v *__restrict__ dst, const uint4v *__restrict__ src,
+__global__ __launch_bounds__(STREAM_THREADS) void scale_vec(uint4v *dst, const uint4v *src,
                                                             uint64_t pieces, uint64_t first, uint64_t factor) {
     const uint64_t p = first + (uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x;
     if (p >= pieces) return;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(STREAM_THREADS) void scale_vec(uint4v *__restrict__
 
 // one element per thread: tails, and tensors whose addresses are not 16-byte aligned
 template <uint32_t K>
-__global__ __launch_bounds__(STREAM_THREADS) void scale_scalar(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(STREAM_THREADS) void scale_scalar(uint8_t *dst, const uint8_t *src,
                                                                uint64_t elems, uint64_t first, uint64_t factor) {
     const uint64_t i = first + (uint64_t)blockIdx.x * STREAM_THREADS + threadIdx.x;
     if (i >= elems) return;

@@ -51,6 +51,34 @@ for ty in (12, 14, 2, 8, 10, 11, 13, 20, 23):
         ok = same_bits(dst.cpu().numpy(), want) if out_dt == t.float32 else same_bits16(bits16(dst), want, "f16")
         assert ok, ("single", ty, out_dt)
 
+# the same single-tensor decode from a captured graph, replayed with new inputs in the same buffers (under a
+# forced schedule with a group start, the kernel's probe reads a line of `dst` that the previous replay wrote; the
+# consumer between the replays is an ordinary reduction over `dst`)
+for ty, out_dt, o_out in ((12, t.float16, o.F16), (8, t.float32, o.F32), (14, t.bfloat16, o.BF16)):
+    n = g.block_elems(ty)
+    blocks = 9 * 8192 // n + 5
+    src = t.empty(blocks * g.block_bytes(ty), dtype=t.uint8, device="cuda")
+    dst = t.empty(blocks * n, dtype=out_dt, device="cuda")
+    side = t.cuda.Stream()
+    with t.cuda.stream(side):
+        g.dequantize_slice(ty, dst, src)            # warm-up outside the capture
+    side.synchronize()
+    gr = t.cuda.CUDAGraph()
+    with t.cuda.graph(gr):
+        g.dequantize_slice(ty, dst, src)
+        g.dequantize_slice(ty, dst, src)            # back to back into the same buffer
+    for rep in range(3):
+        p = synth.random_blocks(ty, blocks, 900 + 10 * ty + rep)
+        src.copy_(t.from_numpy(p))
+        gr.replay()
+        t.cuda.synchronize()
+        want = o.dequantize(ty, p, o_out, threads=4)
+        ok = same_bits(dst.cpu().numpy(), want) if out_dt == t.float32 else \
+            same_bits16(bits16(dst), want, "f16" if out_dt == t.float16 else "bf16")
+        assert ok, ("graph replay", ty, rep)
+        assert bool(t.isfinite(dst.float().sum()))   # eager work on the buffer between the replays
+    del gr
+
 # batch decode: one group of 11 tiles in 4 launches, several tensors with short tiles
 tensors, packed = [], []
 for i, blocks in enumerate((16 * 4 + 1, 7, 16 * 5, 16 + 3)):

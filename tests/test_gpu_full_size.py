@@ -209,7 +209,9 @@ def test_tinyllama_f16_to_q8_0_one_plan_every_byte(torch_cuda, oracle):
         w16 = (t.randn(n, device="cuda", generator=gen) * 0.02).to(t.float16)
         tensors.append((8, w16, t.empty(n // 32 * 34, dtype=t.uint8, device="cuda")))
     b = g.QuantBatch(tensors)
-    assert b.launches == 1
+    # one launch through the tile table; separate allocations that happen to be adjacent in memory form a run, and a
+    # run of 64 Mi elements gets a launch of its own (none of the 90 matrices is that large by itself)
+    assert b.table_launches == 1 and b.launches <= 1 + sum(w.numel() for _, w, _ in tensors) // (64 << 20)
     b.run()
     t.cuda.synchronize()
     from concurrent.futures import ThreadPoolExecutor
