@@ -81,16 +81,14 @@ __device__ __forceinline__ uint32_t cvt_u32_sat(float x) {
     asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
-__device__ __forceinline__ uint32_t sat_u8(float x) { return min(cvt_u32_sat(x), 255u); }
-__device__ __forceinline__ int sat_i8(float x) { return max(-128, min(cvt_i32_sat(x), 127)); }
-// f32::round (half away from zero) as trunc(x + copysign(pred(0.5), x)): equal to it for every
-// float (checked exhaustively for |x| < 512 on the host; beyond that both sides are far outside
-// the i8 range that follows).  A NaN stays a NaN.
-__device__ __forceinline__ float round_away(float x) {
-    return truncf(__fadd_rn(x, copysignf(0.49999997f, x)));
-}
-// f32::min(x, c) for a non-NaN constant c: a NaN x gives c
-__device__ __forceinline__ float min_c(float x, float c) { return x < c ? x : c; }
+__device__ __forceinline__ int clamp_i8(int v) { return max(-128, min(v, 127)); }
+__device__ __forceinline__ int sat_i8(float x) { return clamp_i8(cvt_i32_sat(x)); }
+// f32::round (half away from zero) is trunc(x + copysign(pred(0.5), x)) for every float (checked exhaustively for
+// |x| < 512 on the host; beyond that both sides are far outside the i8 range that follows); a NaN stays a NaN.
+// `f32::round(x) as i32` in one go: the conversion truncates toward zero by itself, so the truncation of round_away
+// is not issued separately (one instruction less per element; the quantizers from 16-bit input are VALU-bound).
+__device__ __forceinline__ int round_away_i32(float x) { return cvt_i32_sat(__fadd_rn(x, copysignf(0.49999997f, x))); }
+// (f32::min(x, c) for a non-NaN constant c gives c for a NaN x: that is fminf / v_min_f32.)
 __device__ __forceinline__ uint32_t f2h_bits(float x) {
     asm volatile("" : "+v"(x));   // keep the producer from being folded into the conversion
     return (uint32_t)__half_as_ushort(__float2half_rn(x));
@@ -141,35 +139,29 @@ __device__ __forceinline__ float group_max_by_abs(const float *x, uint32_t n) {
 }
 template <uint32_t G>
 __device__ __forceinline__ float group_max_abs(const float *x, uint32_t n) {
+    // acc.max(|x|): f32::max ignores a NaN operand, which is what v_max_f32 does (the compiler quiets a possible
+    // signalling NaN first where the value comes straight from memory); one instruction per element
     float m = 0.0f;
-    for (uint32_t k = 0; k < n; ++k) { float a = fabsf(x[k]); m = a > m ? a : m; }   // acc.max(|x|), NaN ignored
-    butterfly<G>([&](auto s) { float o = other_half<s.value>(m); m = o > m ? o : m; });
+    for (uint32_t k = 0; k < n; ++k) m = fmaxf(m, fabsf(x[k]));
+    butterfly<G>([&](auto s) { m = fmaxf(m, other_half<s.value>(m)); });
     return m;
 }
-// min and max in the total order (-0 < +0) with NaN ignored, folded from (f32::MAX, f32::MIN)
-// (structs.rs:101-107), branch-free: a float's bits map to a signed integer
-// key that sorts the same way (flip the magnitude bits of negatives), a NaN maps to a key that can
-// never win against the fold's start value, and the folds are integer min / max.
-__device__ __forceinline__ int order_key(float x) {
-    int b = (int)__float_as_uint(x);
-    return b ^ ((b >> 31) & 0x7FFFFFFF);
-}
-__device__ __forceinline__ float from_order_key(int k) { return __uint_as_float((uint32_t)(k ^ ((k >> 31) & 0x7FFFFFFF))); }
+// min and max with NaN ignored, folded from (f32::MAX, f32::MIN) (structs.rs:101-107): f32::min / f32::max return
+// the other operand when one is a NaN, which is v_min_f32 / v_max_f32 (minNum / maxNum; the compiler quiets a
+// possible signalling NaN first).  For (+0, -0) Rust leaves the result open; the hardware orders -0 below +0, and so
+// does the oracle.  Three instructions per element where integer sort keys took eight.
 template <uint32_t G>
 __device__ __forceinline__ void group_min_max(const float *x, uint32_t n, float &lo, float &hi) {
-    int klo = order_key(3.40282347e+38f), khi = order_key(-3.40282347e+38f);
+    lo = 3.40282347e+38f;
+    hi = -3.40282347e+38f;
     for (uint32_t k = 0; k < n; ++k) {
-        const int key = order_key(x[k]);
-        const bool nan = is_nan(x[k]);
-        klo = min(klo, nan ? 0x7FFFFFFF : key);
-        khi = max(khi, nan ? (int)0x80000000 : key);
+        lo = fminf(lo, x[k]);
+        hi = fmaxf(hi, x[k]);
     }
     butterfly<G>([&](auto s) {
-        klo = min(klo, other_half<s.value>(klo));
-        khi = max(khi, other_half<s.value>(khi));
+        lo = fminf(lo, other_half<s.value>(lo));
+        hi = fmaxf(hi, other_half<s.value>(hi));
     });
-    lo = from_order_key(klo);
-    hi = from_order_key(khi);
 }
 template <uint32_t G>
 __device__ __forceinline__ uint32_t group_or(uint32_t v) {
@@ -194,8 +186,12 @@ __device__ __forceinline__ void pack_nibbles(const uint32_t *q, uint32_t gl, uin
     constexpr uint32_t W = EPL / 4;
     uint32_t w[W];
 #pragma unroll
-    for (uint32_t j = 0; j < W; ++j)
-        w[j] = (q[4 * j] & 0xFu) | ((q[4 * j + 1] & 0xFu) << 8) | ((q[4 * j + 2] & 0xFu) << 16) | ((q[4 * j + 3] & 0xFu) << 24);
+    for (uint32_t j = 0; j < W; ++j) {
+        // low bytes of four registers into one word (three byte permutes), then the low nibbles of all four at once
+        const uint32_t lo = __builtin_amdgcn_perm(q[4 * j + 1], q[4 * j], 0x0c0c0400u);
+        const uint32_t hi = __builtin_amdgcn_perm(q[4 * j + 3], q[4 * j + 2], 0x0c0c0400u);
+        w[j] = __builtin_amdgcn_perm(hi, lo, 0x05040100u) & 0x0F0F0F0Fu;
+    }
 #pragma unroll
     for (uint32_t j = 0; j < W; ++j) {
         // the word of the lane G/2 above (only the lower half of the group uses it)
@@ -225,7 +221,8 @@ struct EncQ4_0 {
         } else {
             float delta = __fdiv_rn(max, -8.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_u8(min_c(__fadd_rn(__fmul_rn(x[k], recip), 8.5f), 15.0f));
+            // `(y + 8.5).min(15.) as u8`: the float minimum (a NaN gives 15) leaves nothing for the cast to clamp from above
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = cvt_u32_sat(fminf(__fadd_rn(__fmul_rn(x[k], recip), 8.5f), 15.0f));
         }
         if (write && gl == 0) st16(blk, hdr);
         pack_nibbles<EPL, G>(q, gl, blk + 2, write);
@@ -249,8 +246,8 @@ struct EncQ4_1 {
             float delta = __fdiv_rn(__fsub_rn(mx, mn), 15.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
             for (uint32_t k = 0; k < EPL; ++k) {
-                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f));
-                q[k] = v < 15 ? v : 15;
+                // `as u8` saturates at 255, `.min(15)` follows: one integer minimum does both
+                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 15u);
             }
         }
         if (write && gl == 0) *(uint32_t *)blk = hdr;
@@ -273,8 +270,7 @@ struct EncQ5_0 {
             float delta = __fdiv_rn(max, -16.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
             for (uint32_t k = 0; k < EPL; ++k) {
-                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(x[k], recip), 16.5f));
-                q[k] = v < 31 ? v : 31;
+                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(x[k], recip), 16.5f)), 31u);
                 bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);   // element e owns bit e of qh
             }
         }
@@ -301,8 +297,7 @@ struct EncQ5_1 {
             float delta = __fdiv_rn(__fsub_rn(mx, mn), 31.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
             for (uint32_t k = 0; k < EPL; ++k) {
-                uint32_t v = sat_u8(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f));
-                q[k] = v < 31 ? v : 31;
+                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 31u);
                 bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);
             }
         }
@@ -315,9 +310,13 @@ struct EncQ5_1 {
 template <uint32_t EPL>
 __device__ __forceinline__ void store_i8(const int *q, uint8_t *p) {   // p 2-byte aligned
 #pragma unroll
-    for (uint32_t j = 0; j < EPL / 4; ++j)
-        st32_a2(p + 4 * j, (uint32_t)(q[4 * j] & 0xFF) | ((uint32_t)(q[4 * j + 1] & 0xFF) << 8) |
-                               ((uint32_t)(q[4 * j + 2] & 0xFF) << 16) | ((uint32_t)(q[4 * j + 3] & 0xFF) << 24));
+    for (uint32_t j = 0; j < EPL / 4; ++j) {
+        // the low bytes of four registers into one word: three byte permutes (selector bytes 0-3 pick from the
+        // second operand, 4-7 from the first)
+        const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * j + 1], (uint32_t)q[4 * j], 0x0c0c0400u);
+        const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * j + 3], (uint32_t)q[4 * j + 2], 0x0c0c0400u);
+        st32_a2(p + 4 * j, __builtin_amdgcn_perm(hi, lo, 0x05040100u));
+    }
 }
 
 // ggml-quants/src/structs/q8_0.rs:23-41
@@ -334,7 +333,7 @@ struct EncQ8_0 {
         } else {
             float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = sat_i8(round_away(__fmul_rn(x[k], recip)));
+            for (uint32_t k = 0; k < EPL; ++k) q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip)));
         }
         if (write) {
             if (gl == 0) st16(blk, hdr);
@@ -359,7 +358,7 @@ struct EncQ8_1 {
         } else {
             delta = __fdiv_rn(amax, 127.0f);
             float recip = __fdiv_rn(1.0f, delta);
-            for (uint32_t k = 0; k < EPL; ++k) { q[k] = sat_i8(round_away(__fmul_rn(x[k], recip))); part += q[k]; }
+            for (uint32_t k = 0; k < EPL; ++k) { q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip))); part += q[k]; }
         }
         int sum = group_add<G>(part);
         if (write) {
@@ -385,7 +384,10 @@ struct EncQ8K {
             float delta = __fdiv_rn(max, -127.0f), recip = __fdiv_rn(1.0f, delta);
             hdr = f2h_bits(delta);
             for (uint32_t k = 0; k < EPL; ++k) {
-                q[k] = sat_i8(min_c(round_away(__fmul_rn(x[k], recip)), 127.0f));
+                const float y = __fmul_rn(x[k], recip);
+                // truncation and the minimum with an integer bound commute, so the bound is applied before the
+                // (truncating) conversion; a NaN becomes 127 either way, as f32::min(NaN, 127.) does
+                q[k] = clamp_i8(cvt_i32_sat(fminf(__fadd_rn(y, copysignf(0.49999997f, y)), 127.0f)));
                 part += q[k];
             }
         }
