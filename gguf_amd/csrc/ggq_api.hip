@@ -155,7 +155,8 @@ const uint64_t kMaxGrid = [] {
 
 // Launch plans (ggq_batch_*) are hybrids.  Tensors of one type that follow each other in the caller's table AND in
 // memory -- the next one's blocks start where the previous one's end, and so do their outputs -- are one run: blocks
-// are independent, so a run decodes as one long tensor.  A run of at least this many elements whose single-tensor
+// are independent, so a run decodes as one long tensor.  A type's only run needs no table at all and is launched as
+// the single tensor it is.  Among several runs of a type, one of at least this many elements whose single-tensor
 // schedule has a group start (schedule.h) leaves the plan's tile table and gets a launch of its own: the table
 // kernel cannot take the group start and runs 4-7 points of the roofline below the single-tensor kernel for those
 // (type, output) pairs, while a launch costs 3-4 us of ramp and drain (measured on 235 Mi-element tensors: 202
@@ -1159,7 +1160,13 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
         }
         for (const PlanRun &r : merged) {
             const uint64_t elems = r.blocks * type_info(r.ty)->elems;
-            if (elems >= kHybridMinElems && (kHybridAny || pick_prefetch(r.ty, out_ty, false, elems).wait != 0)) {
+            // a launch of its own: long runs whose schedule has a group start, and a type's ONLY run (a table with
+            // one entry would add a record load to every workgroup for nothing: one 16 Mi-element tensor decodes at
+            // 0.70-0.72 of the roofline without it, 0.65 with it)
+            size_t of_type = 0;
+            for (const PlanRun &o : merged) of_type += o.ty == r.ty;
+            if (kHybridMinElems != ~0ull &&
+                (of_type == 1 || (elems >= kHybridMinElems && (kHybridAny || pick_prefetch(r.ty, out_ty, false, elems).wait != 0)))) {
                 b->single.push_back({r.ty, (const void *)(uintptr_t)r.src, (void *)(uintptr_t)r.dst, r.blocks});
                 continue;
             }

@@ -67,6 +67,7 @@ def main():
     fe, wr = counter(fetch, "FETCH_SIZE"), counter(write, "WRITE_SIZE")
     tpath = os.path.join(HERE, "traffic.json")
     doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    written = set()
     for k in fe:
         if "deq_batch<ggq::" not in k and "deq_one<ggq::" not in k and "quant_one<ggq::" not in k:
             continue        # helper kernels (the tile table builder) carry no format
@@ -74,9 +75,10 @@ def main():
         read_b = 2.0 * fe[k] * 1024.0
         write_b = wr.get(k, 0.0) * 1024.0
         # a plan can hold a table launch and single-tensor launches of one format: the entry is the larger launch
-        old = doc.get(f"{key}:{fmt}")
-        if old and old.get("round") == tag and old.get("kernel") != k and old["hbm_bytes_per_launch"] > read_b + write_b:
+        old = doc.get(f"{key}:{fmt}") if f"{key}:{fmt}" in written else None
+        if old and old["hbm_bytes_per_launch"] > read_b + write_b:
             continue
+        written.add(f"{key}:{fmt}")
         doc[f"{key}:{fmt}"] = {
             "kernel": k, "round": tag,
             "FETCH_SIZE_KiB_raw": fe[k], "WRITE_SIZE_KiB_raw": wr.get(k),

@@ -251,7 +251,7 @@ def test_batch_every_format_and_output(torch_cuda, oracle, ty, out):
     o_out = {"f32": oracle.F32, "f16": oracle.F16, "bf16": oracle.BF16}[out]
     tensors, packed = _batch_case(t, oracle, ty, sizes, 8100 + ty, out_dt)
     b = g.Batch(tensors, {"f32": g.GGmlType.F32, "f16": g.GGmlType.F16, "bf16": g.GGmlType.BF16}[out])
-    assert b.launches == 1
+    assert b.launches == 1 and b.table_launches == 1        # ten separate tensors: the tile-table kernel
     b.run()
     t.cuda.synchronize()
     for (_, _, d), p in zip(tensors, packed):

@@ -41,8 +41,8 @@ def first_diff(a, b):
 
 
 def plan_entries(tensors, ob, forced=None, min_elems=64 << 20):
-    """The routing rule of ggq_batch_create restated: how many entries (one table launch per type, launches of
-    their own, widenings) a plan with `ob`-byte outputs has.  tensors: [(type, elements)] or [(type, elements,
+    """The routing rule of ggq_batch_create restated: how many entries (one table launch per type with several
+    runs in the table, launches of their own, widenings) a plan with `ob`-byte outputs has.  tensors: [(type, elements)] or [(type, elements,
     adjacent)], adjacent = this tensor's blocks and outputs start where those of the previous tensor of its type
     end (such tensors form one run).  forced: the GGQ_PREFETCH triple if that variable is set; min_elems mirrors
     GGQ_HYBRID_MIN_ELEMS (default = the library's)."""
@@ -65,7 +65,8 @@ def plan_entries(tensors, ob, forced=None, min_elems=64 << 20):
             runs.append([ty, n])
     table = set()
     for ty, n in runs:
-        if grouped(ty, n) and n >= min_elems:
+        only = sum(1 for t2, _ in runs if t2 == ty) == 1           # a type's only run needs no table
+        if min_elems and (only or (grouped(ty, n) and n >= min_elems)):
             entries += 1
         else:
             table.add(ty)
