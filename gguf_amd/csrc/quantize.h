@@ -149,7 +149,7 @@ __device__ __forceinline__ float group_max_abs(const float *x, uint32_t n) {
 // min and max with NaN ignored, folded from (f32::MAX, f32::MIN) (structs.rs:101-107): f32::min / f32::max return
 // the other operand when one is a NaN, which is v_min_f32 / v_max_f32 (minNum / maxNum; the compiler quiets a
 // possible signalling NaN first).  For (+0, -0) Rust leaves the result open; the hardware orders -0 below +0, and so
-// does the oracle.  Three instructions per element where integer sort keys took eight.
+// do the parity tests.  Three instructions per element where integer sort keys took eight.
 template <uint32_t G>
 __device__ __forceinline__ void group_min_max(const float *x, uint32_t n, float &lo, float &hi) {
     lo = 3.40282347e+38f;
