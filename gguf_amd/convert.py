@@ -392,12 +392,48 @@ def _meta_string(text):
     return 8, struct.pack("<Q", len(raw)) + raw
 
 
+def _parse_f64(text):
+    """str::parse::<f64> of the reference: Python's float() minus what Rust refuses (digit separators, padding)."""
+    if re.search(r"[_\s]", text) or text == "":
+        raise ValueError(f"invalid float: {text!r}")
+    return float(text)
+
+
+def _parse_f32(text):
+    """str::parse::<f32>: ONE correctly rounded step from the decimal text (float() then a cast would round twice:
+    to f64, then to f32, which differs for texts within half an f64 step of an f32 tie)."""
+    from fractions import Fraction
+    d = _parse_f64(text)
+    if d != d or d in (float("inf"), float("-inf")) and not re.search(r"\d", text):
+        return np.float32(d)                     # "nan", "inf", "infinity" in any case
+    try:
+        exact = Fraction(text)
+    except (ValueError, ZeroDivisionError):
+        with np.errstate(over="ignore"):
+            return np.float32(d)
+    neg = text.lstrip().startswith("-")
+    mag = abs(exact)
+    if mag == 0:
+        return np.float32(-0.0 if neg else 0.0)
+    e = mag.numerator.bit_length() - mag.denominator.bit_length()       # 2^(e-1) < mag < 2^(e+1)
+    if Fraction(2) ** e > mag:
+        e -= 1
+    quantum = Fraction(2) ** (max(e, -126) - 23)
+    n, rem = divmod(mag, quantum)
+    n = int(n)
+    if rem * 2 > quantum or (rem * 2 == quantum and n & 1):
+        n += 1
+    value = n * quantum
+    out = float("inf") if value >= Fraction(2) ** 128 else float(value)     # exact: value is an f32
+    return np.float32(-out if neg else out)
+
+
 def _meta_value(ty, text):
     """write_val (set_meta.rs:212-249): the value's bytes from its text."""
     if ty == 8:
         return _meta_string(text)
     if ty in _INT_FMT:
-        if not re.fullmatch(r"[+-]?\d+", text):
+        if not re.fullmatch(r"[+-]?\d+" if _INT_RANGE[ty][0] < 0 else r"\+?\d+", text):      # no sign for unsigned types
             raise ValueError(f"invalid integer: {text!r}")
         v = int(text)
         lo, hi = _INT_RANGE[ty]
@@ -405,9 +441,7 @@ def _meta_value(ty, text):
             raise ValueError(f"integer out of range: {text}")
         return ty, struct.pack(_INT_FMT[ty], v)
     if ty in (6, 12):
-        if "_" in text:
-            raise ValueError(f"invalid float: {text!r}")
-        return ty, struct.pack("<f" if ty == 6 else "<d", np.float32(float(text)) if ty == 6 else float(text))
+        return ty, struct.pack("<f", _parse_f32(text)) if ty == 6 else struct.pack("<d", _parse_f64(text))
     if ty == 7:
         if text not in ("true", "false"):
             raise ValueError(f"Invalid bool value: {text}")
@@ -683,9 +717,9 @@ class Content:
         nblk = struct.unpack(_INT_FMT[ty], raw)[0]
         embd, res = f32_key(keys["embedding_scale"]), f32_key(keys["residual_scale"])
         if "embd_scale" in extra:
-            embd = float(extra["embd_scale"])
+            embd = _parse_f64(extra["embd_scale"])
         if "res_scale" in extra:
-            res = float(extra["res_scale"])
+            res = _parse_f64(extra["res_scale"])
         if embd is None or res is None:
             raise ValueError('convert from minicpm requires extra args "embd_scale=<num> res_scale=<num>"')
         res = res / math.sqrt(float(nblk))

@@ -335,3 +335,31 @@ def test_to_llama_end_to_end(tmp_path):
         ty, raw = vals["token_embd.weight"]
         scaled = O.scale(int(ty), raw.view(np.uint16), 2.0)
         assert t.ty == 0 and np.array_equal(t.bytes(), O.dequantize(int(T.F16), scaled.view(np.uint8)).view(np.uint8))
+
+
+def test_meta_numbers_parse_like_rust():
+    """set-meta values and to-llama overrides go through Rust's str::parse: f32 is rounded ONCE from the decimal text
+    (a detour through f64 rounds twice and lands one step off next to a tie), unsigned types take no minus sign, and
+    neither digit separators nor padding are numbers."""
+    import struct
+    from gguf_amd.convert import _meta_value, _parse_f32, _parse_f64
+    up = np.nextafter(np.float32(1), np.float32(2))
+    assert _parse_f32("1.0000000596046447753906251") == up          # just above the tie between 1 and its successor
+    assert np.float32(float("1.0000000596046447753906251")) == np.float32(1)      # ... which the detour misses
+    assert _parse_f32("1.00000005960464477539062") == np.float32(1)                # just below the tie
+    assert _parse_f32("1.000000059604644775390625") == np.float32(1)               # the tie itself: to even
+    rng = np.random.default_rng(3)
+    for bits in rng.integers(0, 2 ** 32, 3000, dtype=np.uint64):
+        v = np.uint32(bits).view(np.float32)
+        if np.isfinite(v):
+            assert _parse_f32(repr(float(v))).view(np.uint32) == np.uint32(bits)
+    assert _parse_f32("3.40282357e38") == np.inf and _parse_f32("3.4028235e38") == np.finfo(np.float32).max
+    assert _parse_f32("7e-46") == 0 and _parse_f32("8e-46").view(np.uint32) == 1 and str(_parse_f32("-0.0")) == "-0.0"
+    assert np.isnan(_parse_f32("NaN")) and _parse_f32("-inf") == -np.inf
+    assert _meta_value(6, "0.1") == (6, struct.pack("<f", np.float32(0.1)))
+    assert _meta_value(0, "+7") == (0, b"\x07") and _meta_value(1, "-0") == (1, b"\x00")
+    for ty, bad in ((0, "-0"), (4, "-1"), (10, "-0"), (6, "1_0"), (12, " 1.0"), (12, "1_0.5")):
+        with pytest.raises(ValueError):
+            _meta_value(ty, bad)
+    with pytest.raises(ValueError):
+        _parse_f64("1_0")
