@@ -346,8 +346,11 @@ def timed_resident(share, steps, warmup, settle_ms, fence, with_events=True):
                 ev[s][k + 1].record()
         else:
             share.step(stream)
-    fence()
+    # this rank's clock stops when ITS GPU has drained; the barrier that follows is not part of anybody's time (the
+    # caller takes the maximum over the ranks, i.e. the time of the slowest one)
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
     kern_ms = None
     if sampled:
         kern_ms = [sum(ev[s][k].elapsed_time(ev[s][k + 1]) for s in sampled) / len(sampled) for k in range(nplans)]
@@ -382,9 +385,10 @@ def streamed_leg(share, local, steps, fence, max_over_ranks):
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        step()                              # ends with ctx.sync(): this rank's copies and decodes are done
+    elapsed = time.perf_counter() - t0
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed = max_over_ranks(elapsed)
     ctx.close()
     return elapsed, staging
 
@@ -569,8 +573,10 @@ def main():
             t0 = time.perf_counter()
             for _ in range(args.gather):
                 full = shard.gather_arenas(arena, world, group)
+            torch.cuda.synchronize()
+            g_dt = time.perf_counter() - t0
             fence()
-            g_elapsed = max_over_ranks(time.perf_counter() - t0) / args.gather
+            g_elapsed = max_over_ranks(g_dt) / args.gather
             # every rank's row must be that rank's arena: compare 64-bit sums of the rows with the owners' own
             mine = share.arena.view(torch.int64).sum().cpu().reshape(1)
             sums = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
