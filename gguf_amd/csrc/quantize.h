@@ -238,18 +238,15 @@ struct EncQ4_1 {
         float mn, mx;
         group_min_max<G>(x, EPL, mn, mx);
         uint32_t q[EPL];
-        uint32_t hdr;
-        if (mn == mx) {
-            hdr = f2h_bits(mn) << 16;
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
-        } else {
-            float delta = __fdiv_rn(__fsub_rn(mx, mn), 15.0f), recip = __fdiv_rn(1.0f, delta);
-            hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
-            for (uint32_t k = 0; k < EPL; ++k) {
-                // `as u8` saturates at 255, `.min(15)` follows: one integer minimum does both
-                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 15u);
-            }
-        }
+        // No branch for the reference's `min == max` case (header (0, min), all codes 0): with delta = 0 there,
+        // recip = inf, every element gives (x - min) * inf = 0 * inf = NaN (or NaN from a NaN or infinite element),
+        // a NaN converts to 0, and f16(0) | f16(min) << 16 is the header -- the general path produces that block.
+        // (delta is selected, not computed, in that case: for min = max = inf the difference would be NaN.)
+        const float delta = mn == mx ? 0.0f : __fdiv_rn(__fsub_rn(mx, mn), 15.0f), recip = __fdiv_rn(1.0f, delta);
+        const uint32_t hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
+        // `as u8` saturates at 255, `.min(15)` follows: one integer minimum does both
+        for (uint32_t k = 0; k < EPL; ++k)
+            q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 15u);
         if (write && gl == 0) *(uint32_t *)blk = hdr;
         pack_nibbles<EPL, G>(q, gl, blk + 4, write);
     }
@@ -263,18 +260,16 @@ struct EncQ5_0 {
         constexpr uint32_t G = N / EPL;
         float max = group_max_by_abs<G>(x, EPL);
         uint32_t q[EPL];
-        uint32_t hdr = 0, bits = 0;
-        if (max == 0.0f) {
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
-        } else {
-            float delta = __fdiv_rn(max, -16.0f), recip = __fdiv_rn(1.0f, delta);
-            hdr = f2h_bits(delta);
-            for (uint32_t k = 0; k < EPL; ++k) {
-                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(x[k], recip), 16.5f)), 31u);
-                bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);   // element e owns bit e of qh
-            }
+        uint32_t bits = 0;
+        // No branch for `max == 0` (an all-zero block): there delta = -0 and recip = -inf, every element is +-0 or
+        // NaN, so x * recip is NaN, which converts to code 0; only the header needs the case (f16(-0) is not 0).
+        const float delta = __fdiv_rn(max, -16.0f), recip = __fdiv_rn(1.0f, delta);
+        const uint32_t hdr = max == 0.0f ? 0u : f2h_bits(delta);
+        for (uint32_t k = 0; k < EPL; ++k) {
+            q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(x[k], recip), 16.5f)), 31u);
+            bits |= (q[k] >> 4) << k;                       // this lane's fifth bits, at 0 .. EPL-1 for now
         }
-        uint32_t qh = group_or<G>(bits);
+        uint32_t qh = group_or<G>(bits << (gl * EPL));       // element e owns bit e of qh
         if (write && gl == 0) { st16(blk, hdr); st32_a2(blk + 2, qh); }
         pack_nibbles<EPL, G>(q, gl, blk + 6, write);
     }
@@ -289,19 +284,15 @@ struct EncQ5_1 {
         float mn, mx;
         group_min_max<G>(x, EPL, mn, mx);
         uint32_t q[EPL];
-        uint32_t hdr, bits = 0;
-        if (mn == mx) {
-            hdr = f2h_bits(mn) << 16;
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
-        } else {
-            float delta = __fdiv_rn(__fsub_rn(mx, mn), 31.0f), recip = __fdiv_rn(1.0f, delta);
-            hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
-            for (uint32_t k = 0; k < EPL; ++k) {
-                q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 31u);
-                bits |= ((q[k] >> 4) & 1u) << (gl * EPL + k);
-            }
+        uint32_t bits = 0;
+        // no branch for `min == max`, for the reason given at EncQ4_1
+        const float delta = mn == mx ? 0.0f : __fdiv_rn(__fsub_rn(mx, mn), 31.0f), recip = __fdiv_rn(1.0f, delta);
+        const uint32_t hdr = f2h_bits(delta) | (f2h_bits(mn) << 16);
+        for (uint32_t k = 0; k < EPL; ++k) {
+            q[k] = min(cvt_u32_sat(__fadd_rn(__fmul_rn(__fsub_rn(x[k], mn), recip), 0.5f)), 31u);
+            bits |= (q[k] >> 4) << k;
         }
-        uint32_t qh = group_or<G>(bits);
+        uint32_t qh = group_or<G>(bits << (gl * EPL));
         if (write && gl == 0) { *(uint32_t *)blk = hdr; *(uint32_t *)(blk + 4) = qh; }
         pack_nibbles<EPL, G>(q, gl, blk + 8, write);
     }
@@ -327,14 +318,11 @@ struct EncQ8_0 {
         constexpr uint32_t G = N / EPL;
         float amax = group_max_abs<G>(x, EPL);
         int q[EPL];
-        uint32_t hdr = 0;
-        if (amax == 0.0f) {
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
-        } else {
-            float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
-            hdr = f2h_bits(delta);
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip)));
-        }
+        // No branch for `amax == 0`: there delta = +0 (header 0) and recip = +inf, every element is +-0 or NaN, so
+        // x * recip is NaN, which converts to 0 -- the all-zero block the reference returns.
+        const float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
+        const uint32_t hdr = f2h_bits(delta);
+        for (uint32_t k = 0; k < EPL; ++k) q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip)));
         if (write) {
             if (gl == 0) st16(blk, hdr);
             store_i8<EPL>(q, blk + 2 + gl * EPL);
@@ -351,18 +339,12 @@ struct EncQ8_1 {
         float amax = group_max_abs<G>(x, EPL);
         int q[EPL];
         int part = 0;
-        float delta = 0.0f;
-        const bool zero = amax == 0.0f;
-        if (zero) {
-            for (uint32_t k = 0; k < EPL; ++k) q[k] = 0;
-        } else {
-            delta = __fdiv_rn(amax, 127.0f);
-            float recip = __fdiv_rn(1.0f, delta);
-            for (uint32_t k = 0; k < EPL; ++k) { q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip))); part += q[k]; }
-        }
+        // no branch for `amax == 0`, as in EncQ8_0: codes 0, sum 0, delta +0, so the header word is 0 as well
+        const float delta = __fdiv_rn(amax, 127.0f), recip = __fdiv_rn(1.0f, delta);
+        for (uint32_t k = 0; k < EPL; ++k) { q[k] = clamp_i8(round_away_i32(__fmul_rn(x[k], recip))); part += q[k]; }
         int sum = group_add<G>(part);
         if (write) {
-            if (gl == 0) *(uint32_t *)blk = zero ? 0u : (f2h_bits(delta) | (f2h_bits(__fmul_rn((float)sum, delta)) << 16));
+            if (gl == 0) *(uint32_t *)blk = f2h_bits(delta) | (f2h_bits(__fmul_rn((float)sum, delta)) << 16);
             store_i8<EPL>(q, blk + 4 + gl * EPL);
         }
     }

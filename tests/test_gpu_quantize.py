@@ -123,6 +123,30 @@ def test_nan_elements_are_ignored_by_the_folds(torch_cuda, oracle, ty):
     check(oracle, ty, gpu_quantize(torch_cuda, ty, x, "f32"), x, "f32")
 
 
+@pytest.mark.parametrize("ty", [2, 3, 6, 7, 8, 15])
+def test_degenerate_blocks(torch_cuda, oracle, ty):
+    """The blocks for which the reference leaves its general path -- all zero (`max == 0`), all equal (`min == max`)
+    -- mixed with NaN elements, made of infinities, or of -0, and blocks that hold an infinity among finite values:
+    the GPU encoders have no branch for most of these cases and must still produce the reference's bytes.  (Q8_1 is
+    left out as in the NaN test: its `sum` header becomes 0 * inf, whose NaN differs between x86 and the GPU.)"""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(13)
+    rows = []
+    z = np.zeros(n, dtype=np.float32); z[2] = np.nan; z[n - 1] = np.nan; rows.append(z)                # zeros and NaN
+    z = np.full(n, -0.0, dtype=np.float32); z[0] = np.nan; rows.append(z)
+    rows.append(np.full(n, np.nan, dtype=np.float32))
+    f = np.full(n, 0.4375, dtype=np.float32); f[5] = np.nan; f[6] = -np.nan; rows.append(f)          # flat and NaN
+    rows.append(np.full(n, np.inf, dtype=np.float32))
+    rows.append(np.full(n, -np.inf, dtype=np.float32))
+    i = np.full(n, np.inf, dtype=np.float32); i[3] = np.nan; rows.append(i)
+    r = (rng.standard_normal(n) * 0.1).astype(np.float32); r[7] = np.inf; rows.append(r)              # one infinity
+    r = (rng.standard_normal(n) * 0.1).astype(np.float32); r[0] = -np.inf; r[9] = np.inf; rows.append(r)
+    z = np.zeros(n, dtype=np.float32); z[1::2] = -0.0; z[4] = np.nan; rows.append(z)
+    rows.append(np.full(n, 1e-45, dtype=np.float32))                                                  # flat subnormal
+    x = np.concatenate(rows)
+    check(oracle, ty, gpu_quantize(torch_cuda, ty, x, "f32"), x, "f32")
+
+
 @pytest.mark.parametrize("ty,kind", [(1, "f32"), (30, "f32"), (30, "f16"), (1, "bf16"), (1, "f16"), (30, "bf16")])
 def test_narrowing(torch_cuda, oracle, ty, kind):
     """f16::from_f32 / bf16::from_f32 per element (half.rs:10-17, 26-33), incl. ties and specials."""
