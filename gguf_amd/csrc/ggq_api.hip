@@ -1232,7 +1232,11 @@ ggq_status ggq_quant_batch_create(const ggq_tensor *tensors, size_t count, uint3
         // F16 / BF16 targets, and runs long enough for a launch of their own: through the table a workgroup starts
         // with a load of its record, which costs the short-lived workgroups of the quantizers 1-13 % (most for the
         // encoders with one load per thread: Q4_0 from f32 5666 against 6542 GB/s), a launch costs ~3 us
-        if (r.ty == GGQ_TYPE_F16 || r.ty == GGQ_TYPE_BF16 || r.blocks * type_info(r.ty)->elems >= kHybridMinElems) {
+        // (and, as in the decode plans, a type's only run needs no table)
+        size_t of_type = 0;
+        for (const PlanRun &o : merged) of_type += o.ty == r.ty;
+        if (r.ty == GGQ_TYPE_F16 || r.ty == GGQ_TYPE_BF16 ||
+            (kHybridMinElems != ~0ull && (of_type == 1 || r.blocks * type_info(r.ty)->elems >= kHybridMinElems))) {
             b->plain.push_back({r.ty, (const void *)(uintptr_t)r.src, (void *)(uintptr_t)r.dst, r.blocks});
             continue;
         }

@@ -188,8 +188,8 @@ ggq_status ggq_batch_create(const ggq_tensor *tensors, size_t count, uint32_t ou
  * and d_dst receives `blocks` packed blocks; both 16-byte aligned (GGQ_MISALIGNED), except that a tensor whose
  * elements and blocks start exactly where those of the previous tensor of its type end continues that tensor's run
  * and needs no alignment of its own.  Target types: those
- * ggq_quantize_device encodes (others: GGQ_UNSUPPORTED); F16 / BF16 targets, and runs of adjacent tensors with
- * 64 Mi elements and more, get one launch per run.  The plan is run, counted and destroyed with ggq_batch_run / _launches / _destroy. */
+ * ggq_quantize_device encodes (others: GGQ_UNSUPPORTED); F16 / BF16 targets, a type's only run, and runs of
+ * adjacent tensors with 64 Mi elements and more, get one launch per run.  The plan is run, counted and destroyed with ggq_batch_run / _launches / _destroy. */
 ggq_status ggq_quant_batch_create(const ggq_tensor *tensors, size_t count, uint32_t in_type,
                                   ggq_batch **out);
 /* Enqueues the plan's kernels on `hip_stream`; does not synchronize.  The device that was
