@@ -77,6 +77,7 @@ SYMBOLS = {
     "ggq_ctx_fence": (_int, [_vp, _vp]),
     "ggq_ctx_wait_stream": (_int, [_vp, _vp]),
     "ggq_dequantize_noalloc": (_int, [_u32, _u32, _vp, _sz, _vp, _sz, _vp]),
+    "ggq_selftest_fast_division": (_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "ggq_sync": (_int, [_vp]),
     "ggq_ctx_destroy": (None, [_vp]),
     "ggq_gguf_parse": (_int, [_vp, _sz, ctypes.POINTER(_vp)]),

@@ -181,6 +181,15 @@ const bool kHybridAny = [] {
     return e && e[0] == '1';
 }();
 
+// GGQ_QUANT_GROUP=k (environment, read once; measurement knob): group start of the single-tensor quantizer kernels
+// over 2^k tiles (0 = off) in place of the per-encoder choice.
+const int kQuantGroup = [] {
+    const char *e = std::getenv("GGQ_QUANT_GROUP");
+    if (!e || !*e) return -1;
+    const long v = std::strtol(e, nullptr, 10);
+    return v < 0 || v > 16 ? -1 : (int)v;
+}();
+
 // GGQ_WIDE_INDEX=1 (environment, read once): take the 64-bit index kernels also for small tensors, so that tests
 // reach them.
 const bool kWideIndex = [] {
@@ -317,7 +326,8 @@ ggq_status launch_quant(uint32_t ty, void *d_dst, const void *d_src, uint64_t bl
             uint64_t n = std::min(kMaxGrid, ntiles - t0);                                          \
             hipLaunchKernelGGL((quant_one<Q, In>), dim3((uint32_t)n), dim3(G::THR), 0, st,         \
                                (const typename In::T *)d_src + t0 * G::ELEMS,                      \
-                               (uint8_t *)d_dst + t0 * G::TBYTES, blocks - t0 * G::TB);            \
+                               (uint8_t *)d_dst + t0 * G::TBYTES, blocks - t0 * G::TB,             \
+                               kQuantGroup < 0 ? QuantGroup<Q>::LOG2 : (uint32_t)kQuantGroup);     \
         }                                                                                          \
         break;                                                                                     \
     }
@@ -1460,6 +1470,23 @@ ggq_status ggq_dequantize_noalloc(uint32_t ty, uint32_t out_ty, void *d_dst, siz
     hipStream_t q = (hipStream_t)hip_stream;
     HIP_TRY(hipMemcpyAsync(nd.ptr, h_src, src_blocks * ti->bytes, hipMemcpyHostToDevice, q));
     return launch_out(ty, out_ty, d_dst, nd.ptr, src_blocks, nd.cus, q);
+}
+
+ggq_status ggq_selftest_fast_division(uint64_t mismatches[5], uint64_t *tested) {
+    if (!mismatches) return GGQ_INVALID;
+    unsigned long long *d = nullptr, h[6] = {0, 0, 0, 0, 0, 0};
+    if (!hip_ok(hipMalloc((void **)&d, sizeof(h)), "hipMalloc")) return GGQ_DEVICE;
+    bool ok = hip_ok(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice), "hipMemcpy");
+    if (ok) {
+        hipLaunchKernelGGL(fast_division_selftest, dim3(16384), dim3(256), 0, nullptr, d);
+        ok = hip_ok(hipGetLastError(), "fast_division_selftest") &&
+             hip_ok(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost), "hipMemcpy");
+    }
+    (void)hipFree(d);
+    if (!ok) return GGQ_DEVICE;
+    for (int k = 0; k < 5; ++k) mismatches[k] = h[k];
+    if (tested) *tested = h[5];
+    return GGQ_OK;
 }
 
 ggq_status ggq_ctx_fence(ggq_ctx *c, void *hip_stream) {

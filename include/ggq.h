@@ -112,7 +112,9 @@ ggq_status ggq_dequantize_device(uint32_t ggml_type, uint32_t out_type,
  * Rust leaves the result open (f32::min / max of +0 and -0) the rule is -0 < +0.
  * Host form: any alignment, synchronous, staged through the same per-device pipeline
  * pool as ggq_dequantize_slice.  Device form: d_src and d_dst 16-byte aligned
- * (GGQ_MISALIGNED otherwise), enqueued on `hip_stream`, not synchronized. */
+ * (GGQ_MISALIGNED otherwise), enqueued on `hip_stream`, not synchronized; the kernels
+ * may load a word of d_dst before they overwrite it (for timing only, as the decode
+ * kernels do), so d_dst must be readable device memory. */
 ggq_status ggq_quantize_slice(uint32_t ggml_type, uint32_t in_type,
                               void *dst, size_t dst_blocks,
                               const void *src, size_t src_elems);
@@ -267,6 +269,15 @@ ggq_status ggq_dequantize_noalloc(uint32_t ggml_type, uint32_t out_type,
                                   void *d_dst, size_t dst_elems,
                                   const void *h_src, size_t src_blocks,
                                   void *hip_stream);
+
+/* Self-test, no counterpart in the reference.  The quantizers divide twice per block (delta = extreme / c and
+ * 1 / delta, ggml-quants/src/structs/q8_0.rs:31-32 and the other formats alike); for blocks of ordinary magnitude
+ * the kernels use shorter instruction sequences than the compiler's general IEEE division.  This call runs those
+ * sequences against the general division for every float in their range on the current device (about a second) and
+ * returns the number of inputs with different bits: mismatches[0..3] for a / 15, a / 31, a / 127, a / -127,
+ * mismatches[4] for 1 / d; *tested (optional) = the inputs checked per constant (0 would mean the kernel did not
+ * run).  All five must be 0 on any GPU the library quantizes on. */
+ggq_status ggq_selftest_fast_division(uint64_t mismatches[5], uint64_t *tested);
 
 #ifdef __cplusplus
 }

@@ -557,11 +557,13 @@ static inline int8_t sat_i8(float x)
 }
 static inline uint8_t min_u8(uint8_t a, uint8_t b) { return a < b ? a : b; }
 
-/* structs.rs:91-94 */
+/* structs.rs:91-94 : acc.max(|x|) ignores a NaN element, quiet or signalling (compiled Rust compares and
+ * selects; C's fmaxf answers a signalling NaN with a NaN, which the next step would then ignore together with
+ * everything folded so far -- hence the explicit comparison, acc itself is never a NaN) */
 static float max_abs(const float *x, int n)
 {
     float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc = fmaxf(acc, fabsf(x[i]));
+    for (int i = 0; i < n; ++i) { float v = fabsf(x[i]); if (v > acc) acc = v; }
     return acc;
 }
 /* structs.rs:96-100 : keeps the sign; a tie keeps the earlier element */

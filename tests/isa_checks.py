@@ -58,7 +58,9 @@ def functions(asm_text):
                 continue
             s = line.strip()
             if s and not s.startswith((";", ".", "//")) and not s.endswith(":"):
-                body.append(s.split(";")[0].strip())
+                ins = s.split(";")[0].strip()
+                # the quantizers' short division sequences carry a tag in the asm comment
+                body.append(ins + " ; ggq:fastdiv" if "ggq:fastdiv" in s else ins)
     return out
 
 
@@ -71,11 +73,19 @@ FORBIDDEN = re.compile(r"^(v_pk_(add|mul|fma)_f32|v_fma_mix\w*)\b")
 FMA = re.compile(r"^(v_fma_f32|v_fmac_f32|v_fma_f64|v_fmac_f64|v_pk_fma_f16|v_fma_f16|v_fmac_f16)\b")
 
 
-def check_arithmetic(funcs):
-    """Returns a list of complaints (empty = fine)."""
+# fused steps of the short divisions per encode call (gguf_amd/csrc/quantize.h: div_const_fast 2, recip_fast 4);
+# Q4_0 and Q5_0 divide by a power of two first, which is a multiplication
+FASTDIV_STEPS = {"EncQ4_0": 4, "EncQ5_0": 4, "EncQ4_1": 6, "EncQ5_1": 6, "EncQ8_0": 6, "EncQ8_1": 6, "EncQ8K": 6}
+
+
+def check_arithmetic(funcs, names=None):
+    """Returns a list of complaints (empty = fine).  Fused multiply-adds may appear in two places only: inside the
+    compiler's division sequence, and as the tagged steps of the quantizers' short divisions -- there exactly
+    FASTDIV_STEPS per encode call (one or two calls per thread), and only in quantizer kernels and the self-test."""
     bad = []
+    names = names or {}
     for name, body in funcs.items():
-        open_div = 0
+        open_div, tagged = 0, 0
         for ins in body:
             if FORBIDDEN.match(ins):
                 bad.append(f"{name}: {ins}")
@@ -83,18 +93,31 @@ def check_arithmetic(funcs):
                 open_div += 1
             elif ins.startswith("v_div_fixup_f32"):
                 open_div = max(0, open_div - 2)
+            elif ins.endswith("ggq:fastdiv"):
+                tagged += 1
             elif FMA.match(ins) and open_div == 0:
                 bad.append(f"{name}: fused multiply-add outside a division sequence: {ins}")
+        pretty = names.get(name, name)
+        m = re.match(r"^void ggq::quant_(?:one|batch)<ggq::(Enc\w+),", pretty)
+        if m:
+            per_call = FASTDIV_STEPS[m.group(1)]
+            if tagged not in (per_call, 2 * per_call):
+                bad.append(f"{pretty}: {tagged} tagged fused steps, expected {per_call} per encode call")
+            if any(ins.startswith("v_cmpx") for ins in body):
+                bad.append(f"{pretty}: a vector compare writes EXEC in a kernel with hand-placed DPP instructions")
+        elif tagged and "fast_division_selftest" not in pretty:
+            bad.append(f"{pretty}: tagged fused steps outside the quantizers")
     return bad
 
 
 def check_group_start(funcs, names):
-    """Every deq_one<F, O, ...>: before its first tile load (global_load_dwordx4) it must contain, in this order, a
-    scalar ONE-dword load (the probe of the destination), a wait for it, the opaque `v_and_b32 v, 0, v` and the
-    v_readfirstlane that feeds the result into the source address."""
+    """Every deq_one<F, O, ...> and quant_one<Q, In, ...>: before its first tile load (global_load_dwordx4) it must
+    contain, in this order, a scalar ONE-dword load from memory other than the kernel arguments (the probe of the
+    destination), a wait for it, the opaque `v_and_b32 v, 0, v` and the v_readfirstlane that feeds the result into
+    the source address."""
     bad, seen = [], 0
     for name, body in funcs.items():
-        if not names[name].startswith("void ggq::deq_one<"):
+        if not names[name].startswith(("void ggq::deq_one<", "void ggq::quant_one<")):
             continue
         seen += 1
         try:
@@ -104,7 +127,9 @@ def check_group_start(funcs, names):
             continue
         head = body[:first_tile]
         try:
-            i_probe = next(i for i, s in enumerate(head) if re.match(r"^s_load_dword\s+s\d+,", s))
+            # (s[0:1] holds the kernel argument pointer: a one-dword ARGUMENT load, e.g. quant_one's group size, is
+            # not the probe)
+            i_probe = next(i for i, s in enumerate(head) if re.match(r"^s_load_dword\s+s\d+, (?!s\[0:1\])", s))
             i_wait = next(i for i, s in enumerate(head) if i > i_probe and s.startswith("s_waitcnt") and "lgkmcnt(0)" in s)
             i_and = next(i for i, s in enumerate(head) if i > i_wait and re.match(r"^v_and_b32\s+v\d+, 0, v\d+", s))
             next(i for i, s in enumerate(head) if i > i_and and s.startswith("v_readfirstlane_b32"))
@@ -113,8 +138,8 @@ def check_group_start(funcs, names):
             continue
         if any(s.startswith(("global_load_dword ", "flat_load_dword ", "buffer_load_dword ")) for s in head[:i_and]):
             bad.append(f"{names[name]}: the probe went to the vector memory path")
-    if seen == 0:
-        bad.append("no deq_one kernel found")
+    if seen < 40:
+        bad.append(f"only {seen} deq_one / quant_one kernels found")
     return bad
 
 

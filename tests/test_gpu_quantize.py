@@ -123,6 +123,79 @@ def test_nan_elements_are_ignored_by_the_folds(torch_cuda, oracle, ty):
     check(oracle, ty, gpu_quantize(torch_cuda, ty, x, "f32"), x, "f32")
 
 
+@pytest.mark.parametrize("ty", QUANT)
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_signalling_nan_elements_are_ignored_like_quiet_ones(torch_cuda, oracle, ty, kind):
+    """f32::max / f32::min / `>` of the reference make no difference between quiet and signalling NaN elements
+    (structs.rs:91-107); the GPU's v_max_f32 / v_min_f32 do unless the operand was quieted first.  Signalling
+    patterns of the input type at the start, in the middle and at the end of ordinary blocks."""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(17 + ty)
+    x = (rng.standard_normal(40 * n) * 0.7).astype(np.float32)
+    arr = to_in(oracle, x, kind).copy()
+    snan = {"f32": [0x7FA00000, 0xFF800001, 0x7F800400], "f16": [0x7D00, 0xFC01, 0x7C40],
+            "bf16": [0x7FA0, 0xFF81, 0x7F90]}[kind]
+    bits = arr.view(np.uint32) if kind == "f32" else arr
+    for b, pos in enumerate([0, 1, n // 2, n - 1, 3, n - 2, 7, 8]):
+        bits[(3 * b) * n + pos] = snan[b % 3]
+    bits[30 * n + 4] = snan[0]; bits[30 * n + 5] = snan[1]            # two in one lane's elements
+    check(oracle, ty, gpu_quantize(torch_cuda, ty, arr, kind), arr, kind)
+
+
+@pytest.mark.parametrize("ty", [3, 7, 8, 9])
+def test_every_bf16_pattern_through_the_quieting_conversion(torch_cuda, oracle, ty):
+    """The encoders that fold with v_min_f32 / v_max_f32 widen bf16 input with the hardware conversion (which quiets
+    a signalling NaN) instead of a 16-bit shift.  One block per bf16 pattern p: [p, the power of two above |p|, 0 ...]
+    -- p's code tells its value to 7 bits; subnormal patterns alone in their block (a conversion that flushed them
+    would give code 0 instead of a saturated one); NaN patterns are ignored, infinities take the degenerate path (left out for Q8_1, whose `sum` header is
+    then 0 * inf, a NaN whose bits differ between x86 and the GPU)."""
+    n = oracle.block_elems(ty)
+    pats = np.arange(65536, dtype=np.uint32)
+    exp = (pats >> 7) & 0xFF
+    if ty == 9:
+        pats = pats[exp != 0xFF]
+        exp = (pats >> 7) & 0xFF
+    # subnormal patterns stand alone in their block: 1 / delta overflows there, every non-zero element saturates, and
+    # a flushed element would show as code 0
+    above = np.where(exp >= 0xFE, 0x7F7F, np.where(exp == 0, 0, (exp + 1) << 7)).astype(np.uint16)
+    arr = np.zeros((pats.size, n), dtype=np.uint16)
+    arr[:, 0] = pats.astype(np.uint16)
+    arr[:, 1] = above
+    arr[:, 5] = np.where(above != 0, 0x8000 | above, 0)   # a negative companion so that min/max formats see a span
+    arr = arr.reshape(-1)
+    check(oracle, ty, gpu_quantize(torch_cuda, ty, arr, "bf16"), arr, "bf16")
+
+
+@pytest.mark.parametrize("ty", QUANT)
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_blocks_at_the_ends_of_the_ordinary_range(torch_cuda, oracle, ty, kind):
+    """The encoders take short division sequences when every block of a wave has its magnitude (largest element, or
+    max - min) within 2^-100 ..= 2^100, and the general division otherwise.  Blocks scaled to either side of both
+    limits, a few exactly on them, alone in their wave and mixed with ordinary blocks, must give the reference's
+    bytes on both paths.  (f16 input cannot reach the limits.)"""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(23 + ty)
+    per_wave = 64 * (4 if kind == "f32" else 8) // n or 1          # blocks one wave encodes per load
+    rows = []
+
+    def block(scale):
+        b = rng.standard_normal(n).astype(np.float32)
+        b /= np.abs(b).max()
+        if ty in (3, 7):                                             # min/max formats: the range is on max - min
+            b = (b - b.min()) / np.float32(b.max() - b.min())
+        return (b * np.float32(scale)).astype(np.float32)
+
+    scales = [2.0 ** e for e in (-104, -101, -100, -99, -96, 96, 99, 100, 101, 104)]
+    scales += [float(np.nextafter(np.float32(2.0 ** -100), np.float32(0))), float(np.nextafter(np.float32(2.0 ** 100), np.float32(np.inf)))]
+    for s in scales:                                                 # a whole wave (and more) of one scale
+        rows += [block(s) for _ in range(2 * per_wave + 1)]
+    for s in scales:                                                 # single extreme blocks among ordinary ones
+        rows += [block(1.0) for _ in range(per_wave)] + [block(s)] + [block(0.01) for _ in range(3)]
+    x = np.concatenate(rows)
+    arr = to_in(oracle, x, kind)
+    check(oracle, ty, gpu_quantize(torch_cuda, ty, arr, kind), arr, kind)
+
+
 @pytest.mark.parametrize("ty", [2, 3, 6, 7, 8, 15])
 def test_degenerate_blocks(torch_cuda, oracle, ty):
     """The blocks for which the reference leaves its general path -- all zero (`max == 0`), all equal (`min == max`)

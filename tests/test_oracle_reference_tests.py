@@ -91,3 +91,20 @@ def test_layout_names():                            # types.rs:35-62
     doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "type_table.json")))
     names = {t["id"]: t["name"] for t in doc["types"]}
     assert names[2] == "q40" and names[12] == "q4k" and names[20] == "iq4nl" and names[15] == "q8k"
+
+
+@pytest.mark.parametrize("ty", [2, 3, 6, 7, 8, 9, 15])
+def test_signalling_nan_elements_fold_like_quiet_ones(oracle, ty):
+    """structs.rs:91-107: `acc.max(x.abs())`, `x.abs() > acc.abs()` and f32::min / f32::max skip a NaN element; the
+    compiled reference compares and selects, so a signalling NaN is skipped like a quiet one.  (C's fmaxf answers a
+    signalling NaN with a NaN and the fold then forgets what it held: the oracle once did that.)  Every position of
+    a block, each signalling pattern against the same block with a quiet NaN in its place."""
+    n = oracle.block_elems(ty)
+    rng = np.random.default_rng(5 + ty)
+    base = (rng.standard_normal(n) * 0.7).astype(np.float32)
+    for pos in range(n):
+        for pat in (0x7FA00000, 0xFF800001, 0x7F800400):
+            s = base.copy(); s.view(np.uint32)[pos] = pat
+            q = base.copy(); q[pos] = np.nan
+            a, b = oracle.quantize(ty, s), oracle.quantize(ty, q)
+            assert np.array_equal(a, b), (pos, hex(pat))

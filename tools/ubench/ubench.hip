@@ -8,7 +8,8 @@
 //   sw, swb period x lead sweep of the single-tensor / table kernel   (needs a filter such as "sw Q4K_f16")
 //   gw      group-start sweep of the single-tensor kernel             (needs a filter such as "gw Q6K_f16")
 //   sdeq    workgroup shape of the decode kernel (threads x stores per thread), Q4_K and Q4_0
-//   quant   every encoder x input type: one tensor per launch and through a tile table
+//   quant   every encoder x input type: one tensor per launch ("single", shipped group start), through a tile table
+//           ("table"), and with group starts of 1 ... 128 tiles ("qgw")
 //   stream  widen, narrow, the permute_qk row gather, scale
 // Environment: UBENCH_REP = launches per sample (default 3; a long run of one kernel behind itself can behave
 // differently from three launches behind some other variant); UBENCH_COLD=1 = a 2 GiB read with plain (cache-
@@ -231,8 +232,15 @@ static void add_quant(const Ctx &c, const char *qname, const char *iname) {
     uint8_t *dst = c.d_q;
     const std::vector<Foot> foot = {{src, blocks * Q::N * sizeof(TI), "elements"}, {dst, blocks * Q::BYTES, "packed output"}};
     c.vs->push_back({std::string("quant ") + qname + " from " + iname + " single", bytes,
-                     [=](hipStream_t s) { hipLaunchKernelGGL((quant_one<Q, In>), dim3((unsigned)ntiles), dim3(G::THR), 0, s, src, dst, blocks); },
+                     [=](hipStream_t s) { hipLaunchKernelGGL((quant_one<Q, In>), dim3((unsigned)ntiles), dim3(G::THR), 0, s, src, dst, blocks, QuantGroup<Q>::LOG2); },
                      foot, {}});
+    c.vs->push_back({std::string("quant ") + qname + " from " + iname + " qgw 1 (no group start)", bytes,
+                     [=](hipStream_t s) { hipLaunchKernelGGL((quant_one<Q, In>), dim3((unsigned)ntiles), dim3(G::THR), 0, s, src, dst, blocks, 0u); },
+                     foot, {}});
+    for (uint32_t w = 1; w <= 7; ++w)       // group start over 2^w tiles (selected with the word "qgw")
+        c.vs->push_back({std::string("quant ") + qname + " from " + iname + " qgw " + std::to_string(1u << w), bytes,
+                         [=](hipStream_t s) { hipLaunchKernelGGL((quant_one<Q, In>), dim3((unsigned)ntiles), dim3(G::THR), 0, s, src, dst, blocks, w); },
+                         foot, {}});
     std::vector<TileRef> tab(ntiles);
     for (uint64_t t = 0; t < ntiles; ++t) {
         const uint64_t nblk = std::min<uint64_t>(G::TB, blocks - t * G::TB);
