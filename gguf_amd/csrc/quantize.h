@@ -246,11 +246,27 @@ __device__ __forceinline__ float group_max_by_abs(const float *x, uint32_t n) {
     // is in the later half).  The two comparisons land in scalar registers, the tie rule is scalar mask
     // arithmetic, and one select applies it: four vector instructions per step.  No value here is a NaN.
     butterfly<G>([&](auto m) {
-        const float other = other_half<m.value>(best);
-        const uint64_t larger = __builtin_amdgcn_ballot_w64(fabsf(other) > fabsf(best));
-        const uint64_t equal = __builtin_amdgcn_ballot_w64(fabsf(other) == fabsf(best));
-        const uint64_t take = larger | (equal & later_lanes<m.value>());
-        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(other), "s"(take));
+        if constexpr (m.value >= 16) {
+            // across rows of 16 lanes and halves of 32 (Q8K): one swap instruction leaves the earlier half's value
+            // in r[0] and the later half's in r[1] on both sides -- no trip through the LDS crossbar, and the tie
+            // rule needs no lane mask
+            const uint32_t bits = __float_as_uint(best);
+            float early, late;
+            if constexpr (m.value == 16) {
+                const auto r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+                early = __uint_as_float(r[0]); late = __uint_as_float(r[1]);
+            } else {
+                const auto r = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                early = __uint_as_float(r[0]); late = __uint_as_float(r[1]);
+            }
+            best = fabsf(late) > fabsf(early) ? late : early;
+        } else {
+            const float other = other_half<m.value>(best);
+            const uint64_t larger = __builtin_amdgcn_ballot_w64(fabsf(other) > fabsf(best));
+            const uint64_t equal = __builtin_amdgcn_ballot_w64(fabsf(other) == fabsf(best));
+            const uint64_t take = larger | (equal & later_lanes<m.value>());
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(best) : "v"(best), "v"(other), "s"(take));
+        }
     });
     return best;
 }
@@ -585,8 +601,9 @@ struct EncQ8K {
 // tiles on 1 Gi elements, taken after the instruction counts had come down (tools/ubench/sweep_quant_shapes.sh and
 // the "qgw" variants of tools/ubench).  Without a group start small tiles with ONE load per thread win for f32 input
 // (82-85 % of 8 TB/s) and 128 x 2 for 16-bit input (79-82 %); with it two loads per thread win everywhere
-// (84-87 % for groups of 16-32 tiles; one load per thread then loses 12 points), except for Q8K, which no schedule
-// moves from 77-78 %.  Through a tile table (quant_batch, no group start) the same shapes reach 82-85 %.
+// (84-87 % for groups of 16-32 tiles; one load per thread then loses 12 points; Q8K 80-82 % for groups of 4-16 once
+// its wide reduction steps stopped going through LDS).  Through a tile table (quant_batch, no group start) the same
+// shapes reach 80-85 %.
 #if defined(GGQ_QSHAPE_THR) && defined(GGQ_QSHAPE_LPT)
 // measurement builds (tools/ubench): one shape for every (encoder, input type) whose tiles it fits, the default elsewhere
 template <class Q, class In> struct QuantShape {
@@ -603,9 +620,9 @@ template <> struct QuantShape<EncQ8_0, InF16> { static constexpr uint32_t THR = 
 template <> struct QuantShape<EncQ8_0, InBF16> { static constexpr uint32_t THR = 128, LPT = 2; };
 #endif
 
-// groups of 2^5 = 32 tiles start together (quant_one's `wait`); Q8K: none
+// groups of 2^5 = 32 tiles start together (quant_one's `wait`); Q8K, whose tiles hold 8 blocks: 8 tiles
 template <class Q> struct QuantGroup { static constexpr uint32_t LOG2 = 5; };
-template <> struct QuantGroup<EncQ8K> { static constexpr uint32_t LOG2 = 0; };
+template <> struct QuantGroup<EncQ8K> { static constexpr uint32_t LOG2 = 3; };
 
 template <class Q, class In>
 struct QuantGeom {

@@ -25,7 +25,7 @@ while time.perf_counter() < t_end:
     x.mul_(1.0)
     torch.cuda.synchronize()
 
-for ty in (T.Q4_0, T.Q8_0):
+for ty in (T.Q4_0, T.Q4_1, T.Q5_0, T.Q5_1, T.Q8_0, T.Q8_1):
     dst = torch.empty(n // 32 * g.block_bytes(ty), dtype=torch.uint8, device="cuda")
     for _ in range(reps):
         g.quantize_slice(ty, dst, x)
@@ -35,6 +35,12 @@ torch.cuda.synchronize()
 h = torch.empty(n, dtype=torch.float16, device="cuda")
 for _ in range(reps):
     g.quantize_slice(T.F16, h.view(torch.uint8), x)            # narrow f32 -> f16
+for ty in (T.Q4_0, T.Q5_1, T.Q8_0):                            # quantizers from f16 input
+    dst = torch.empty(n // 32 * g.block_bytes(ty), dtype=torch.uint8, device="cuda")
+    for _ in range(reps):
+        g.quantize_slice(ty, dst, h)
+    bytes_per_launch[f"quant_one<ggq::Enc{ty.name}, ggq::InF16"] = n * 2 + dst.numel()
+torch.cuda.synchronize()
 bytes_per_launch["narrow_vec<ggq::InF32, ggq::OutF16"] = n * 6
 for _ in range(reps):
     g.dequantize_slice(T.F16, x, h.view(torch.uint8))          # widen f16 -> f32

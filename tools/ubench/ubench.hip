@@ -8,6 +8,7 @@
 //   sw, swb period x lead sweep of the single-tensor / table kernel   (needs a filter such as "sw Q4K_f16")
 //   gw      group-start sweep of the single-tensor kernel             (needs a filter such as "gw Q6K_f16")
 //   sdeq    workgroup shape of the decode kernel (threads x stores per thread), Q4_K and Q4_0
+//   sgw     the same shapes with a group start of 4 ... 128 tiles in place of the shipped schedule (Q4_K, Q6_K)
 //   quant   every encoder x input type: one tensor per launch ("single", shipped group start), through a tile table
 //           ("table"), and with group starts of 1 ... 128 tiles ("qgw")
 //   stream  widen, narrow, the permute_qk row gather, scale
@@ -209,6 +210,33 @@ static void add_shape(const Ctx &c, const char *fname, uint32_t ty) {
                      [=](hipStream_t s) { hipLaunchKernelGGL((deq_one_s<F, O, THR, S>), dim3(grid), dim3(THR), 0, s, src, dst, blocks, pf); },
                      {packed_foot(src, blocks, F::BYTES), {dst, blocks * F::N * sizeof(typename O::T), "decoded output"}}, {}});
 }
+// the same shapes with a group start in place of the shipped schedule ("sgw"): 2^w tiles, no burst
+template <class F, class O, int THR, int S>
+static void add_shape_gw(const Ctx &c, const char *fname) {
+    typedef SGeom<F, O, THR, S> G;
+    const uint64_t blocks = c.elems / F::N;
+    const unsigned grid = (unsigned)((blocks + G::TB - 1) / G::TB);
+    const double bytes = (double)c.elems * ((double)F::BYTES / F::N + sizeof(typename O::T));
+    const uint8_t *src = c.d_in;
+    typename O::T *dst = (typename O::T *)c.d_out;
+    for (uint32_t w : {2u, 3u, 4u, 5u, 6u, 7u}) {
+        char label[112];
+        std::snprintf(label, sizeof label, "sgw %s_%s thr%d S%d W%u", fname, out_name<O>(), THR, S, 1u << w);
+        const Prefetch pf{0, 0, w};
+        c.vs->push_back({label, bytes,
+                         [=](hipStream_t s) { hipLaunchKernelGGL((deq_one_s<F, O, THR, S>), dim3(grid), dim3(THR), 0, s, src, dst, blocks, pf); },
+                         {packed_foot(src, blocks, F::BYTES), {dst, blocks * F::N * sizeof(typename O::T), "decoded output"}}, {}});
+    }
+}
+template <class F, class O>
+static void add_shapes_gw(const Ctx &c, const char *fname) {
+    add_shape_gw<F, O, 512, 2>(c, fname);
+    add_shape_gw<F, O, 256, 2>(c, fname);
+    add_shape_gw<F, O, 128, 2>(c, fname);
+    add_shape_gw<F, O, 256, 1>(c, fname);
+    add_shape_gw<F, O, 256, 4>(c, fname);
+    add_shape_gw<F, O, 128, 4>(c, fname);
+}
 template <class F, class O>
 static void add_shapes(const Ctx &c, const char *fname, uint32_t ty) {
     add_shape<F, O, 512, 2>(c, fname, ty);
@@ -328,6 +356,11 @@ int main(int argc, char **argv) {
         add_shapes<Q4_0, OutF32>(c, "Q4_0", GGQ_TYPE_Q4_0);
         add_shapes<Q4_0, OutF16>(c, "Q4_0", GGQ_TYPE_Q4_0);
     }
+    if (has("sgw")) {
+        add_shapes_gw<Q4K, OutF32>(c, "Q4K");
+        add_shapes_gw<Q6K, OutF32>(c, "Q6K");
+        add_shapes_gw<Q4K, OutF16>(c, "Q4K");
+    }
     if (has("quant")) {
 #define XQ(Q) add_quant<Q, InF32>(c, #Q, "f32"); add_quant<Q, InF16>(c, #Q, "f16"); add_quant<Q, InBF16>(c, #Q, "bf16");
         XQ(EncQ4_0) XQ(EncQ4_1) XQ(EncQ5_0) XQ(EncQ5_1) XQ(EncQ8_0) XQ(EncQ8_1) XQ(EncQ8K)
@@ -373,7 +406,7 @@ int main(int argc, char **argv) {
         }
     }
     {   // name filter: selection words that are not family names keep the variants whose names hold any of them
-        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "quant", "stream"};
+        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "sgw", "quant", "stream"};
         std::vector<std::string> pats;
         size_t at = 0;
         while (at <= sel.size()) {
