@@ -1,6 +1,6 @@
 // shapes.h -- measurement-only kernels of the A/B harness (tools/ubench): the shipped tile decode with the
 // workgroup shape as a template parameter, and the plain memory streams it is compared with.  Not part of the
-// library.  (The many other experimental kernels of earlier rounds -- table-free batch forms, gated starts, the
+// library.  (The many other experimental kernels of earlier versions -- table-free batch forms, gated starts, the
 // LDS-free Q4_K decoder, chunk-strided stores ... -- were measured, recorded in profiles/EXPERIMENTS.md and removed
 // from the tree; git history keeps them.)
 #pragma once
