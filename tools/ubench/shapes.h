@@ -79,6 +79,34 @@ __global__ __launch_bounds__(THR) void deq_one_s(const uint8_t *__restrict__ src
     asm volatile("" ::"v"(touch));
 }
 
+// ---- F16 / BF16 sources as 64-byte "blocks" of 32 elements through the tile kernel (measurement: the library widens
+// them with widen_vec, no LDS).  The decode is the conversion itself; the scale is unused.
+template <bool BF16SRC>
+struct HalfBlocks {
+    static constexpr uint32_t N = 32, BYTES = 64;
+    template <class R>
+    static __device__ __forceinline__ Scale scale(const R &, uint32_t, uint32_t) { return {0.0f, 0.0f}; }
+    template <int G, class R>
+    static __device__ __forceinline__ void vals(const R &r, uint32_t b, uint32_t e, Scale, float (&y)[4 * G]) {
+        uint32_t q[2 * G];
+        r.template words<2 * G>(b + 2 * e, q);
+#pragma unroll
+        for (int g = 0; g < 2 * G; ++g) {
+            if (BF16SRC) {
+                y[2 * g] = __uint_as_float(q[g] << 16);
+                y[2 * g + 1] = __uint_as_float(q[g] & 0xFFFF0000u);
+            } else {
+                y[2 * g] = h2f(q[g] & 0xFFFFu);
+                y[2 * g + 1] = h2f(q[g] >> 16);
+            }
+        }
+    }
+    template <class R>
+    static __device__ __forceinline__ void dec4(const R &r, uint32_t b, uint32_t e, float (&y)[4]) {
+        vals<1>(r, b, e, scale(r, b, e), y);
+    }
+};
+
 // ---- plain streams: one-shot grids, THR threads, one 16-byte piece per thread ------------------------
 template <int THR>
 __global__ __launch_bounds__(THR) void k_fill(uint4v *dst, uint64_t n16) {

@@ -9,6 +9,7 @@
 //   gw      group-start sweep of the single-tensor kernel             (needs a filter such as "gw Q6K_f16")
 //   sdeq    workgroup shape of the decode kernel (threads x stores per thread), Q4_K and Q4_0
 //   sgw     the same shapes with a group start of 4 ... 128 tiles in place of the shipped schedule (Q4_K, Q6_K)
+//   half    F16 -> f32 as 64-byte blocks through the tile kernel under several schedules (the library uses widen_vec)
 //   quant   every encoder x input type: one tensor per launch ("single", shipped group start), through a tile table
 //           ("table"), and with group starts of 1 ... 128 tiles ("qgw")
 //   stream  widen, narrow, the permute_qk row gather, scale
@@ -356,6 +357,16 @@ int main(int argc, char **argv) {
         add_shapes<Q4_0, OutF32>(c, "Q4_0", GGQ_TYPE_Q4_0);
         add_shapes<Q4_0, OutF16>(c, "Q4_0", GGQ_TYPE_Q4_0);
     }
+    if (has("half")) {      // F16 -> f32 through the tile kernel: no schedule, bursts, group starts (against "stream widen")
+        for (uint32_t w : {0u, 2u, 3u, 4u, 5u, 6u})
+            for (uint32_t l : {0u, 512u, 2048u}) {
+                char label[112];
+                std::snprintf(label, sizeof label, "half F16_f32 tile W%u %s%u", w ? 1u << w : 0u, l ? "P1 L" : "off ", l);
+                add_one<HalfBlocks<false>, OutF32>(c, label, l ? Prefetch{1, l, w} : Prefetch{0, 0, w});
+            }
+        add_one<HalfBlocks<false>, OutF32>(c, "half F16_f32 tile burst P512 L1024", Prefetch{512, 1024});
+        add_one<HalfBlocks<false>, OutF32>(c, "half F16_f32 tile burst P1024 L2048", Prefetch{1024, 2048});
+    }
     if (has("sgw")) {
         add_shapes_gw<Q4K, OutF32>(c, "Q4K");
         add_shapes_gw<Q6K, OutF32>(c, "Q6K");
@@ -406,7 +417,7 @@ int main(int argc, char **argv) {
         }
     }
     {   // name filter: selection words that are not family names keep the variants whose names hold any of them
-        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "sgw", "quant", "stream"};
+        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "sgw", "half", "quant", "stream"};
         std::vector<std::string> pats;
         size_t at = 0;
         while (at <= sel.size()) {
