@@ -107,6 +107,30 @@ struct HalfBlocks {
     }
 };
 
+// ---- widen_vec (f16 -> f32) with the steps per thread and a group start as parameters ----------------------
+template <int S>
+__global__ __launch_bounds__(STREAM_THREADS) void widen_s(const uint2v *__restrict__ src, float *__restrict__ dst,
+                                                          uint64_t n4, uint32_t wait) {
+    if (wait) {
+        const uint64_t first = (((uint64_t)blockIdx.x >> wait) << wait) * STREAM_THREADS * S * 4;
+        src += group_wait(dst + first);
+    }
+    const uint64_t base = (uint64_t)blockIdx.x * STREAM_THREADS * S + threadIdx.x;
+    uint2v v[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + k * STREAM_THREADS;
+        if (i < n4) v[k] = __builtin_nontemporal_load(src + i);
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        uint64_t i = base + k * STREAM_THREADS;
+        if (i >= n4) continue;
+        float y[4] = {h2f(v[k].x & 0xFFFFu), h2f(v[k].x >> 16), h2f(v[k].y & 0xFFFFu), h2f(v[k].y >> 16)};
+        OutF32::store<true>(dst + 4 * i, y);
+    }
+}
+
 // ---- plain streams: one-shot grids, THR threads, one 16-byte piece per thread ------------------------
 template <int THR>
 __global__ __launch_bounds__(THR) void k_fill(uint4v *dst, uint64_t n16) {

@@ -10,6 +10,7 @@
 //   sdeq    workgroup shape of the decode kernel (threads x stores per thread), Q4_K and Q4_0
 //   sgw     the same shapes with a group start of 4 ... 128 tiles in place of the shipped schedule (Q4_K, Q6_K)
 //   half    F16 -> f32 as 64-byte blocks through the tile kernel under several schedules (the library uses widen_vec)
+//   wsw     widen f16 -> f32 with 1, 2, 4 steps per thread and group starts of 4 ... 64 pieces
 //   quant   every encoder x input type: one tensor per launch ("single", shipped group start), through a tile table
 //           ("table"), and with group starts of 1 ... 128 tiles ("qgw")
 //   stream  widen, narrow, the permute_qk row gather, scale
@@ -367,6 +368,23 @@ int main(int argc, char **argv) {
         add_one<HalfBlocks<false>, OutF32>(c, "half F16_f32 tile burst P512 L1024", Prefetch{512, 1024});
         add_one<HalfBlocks<false>, OutF32>(c, "half F16_f32 tile burst P1024 L2048", Prefetch{1024, 2048});
     }
+    if (has("wsw")) {       // widen f16 -> f32: steps per thread x group start
+        const uint2v *src = (const uint2v *)c.d_in;
+        float *dst = (float *)c.d_out;
+        const uint64_t n4 = elems / 4;
+        auto add = [&](auto steps, uint32_t w) {
+            constexpr int S = decltype(steps)::value;
+            const unsigned grid = (unsigned)((n4 + STREAM_THREADS * S - 1) / (STREAM_THREADS * S));
+            vs.push_back({"wsw widen f16 -> f32 steps " + std::to_string(S) + " group " + std::to_string(w ? 1u << w : 0u), (double)elems * 6,
+                          [=](hipStream_t s) { hipLaunchKernelGGL((widen_s<S>), dim3(grid), dim3(STREAM_THREADS), 0, s, src, dst, n4, w); },
+                          {{src, elems * 2, "f16 input"}, {dst, elems * 4, "f32 output"}}, {}});
+        };
+        for (uint32_t w : {0u, 2u, 3u, 4u, 5u, 6u}) {
+            add(std::integral_constant<int, 1>(), w);
+            add(std::integral_constant<int, 2>(), w);
+            add(std::integral_constant<int, 4>(), w);
+        }
+    }
     if (has("sgw")) {
         add_shapes_gw<Q4K, OutF32>(c, "Q4K");
         add_shapes_gw<Q6K, OutF32>(c, "Q6K");
@@ -417,7 +435,7 @@ int main(int argc, char **argv) {
         }
     }
     {   // name filter: selection words that are not family names keep the variants whose names hold any of them
-        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "sgw", "half", "quant", "stream"};
+        static const char *fam[] = {"base", "ship", "sw", "swb", "gw", "sdeq", "sgw", "half", "wsw", "quant", "stream"};
         std::vector<std::string> pats;
         size_t at = 0;
         while (at <= sel.size()) {
