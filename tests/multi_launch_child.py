@@ -79,6 +79,34 @@ for ty, out_dt, o_out in ((12, t.float16, o.F16), (8, t.float32, o.F32), (14, t.
         assert bool(t.isfinite(dst.float().sum()))   # eager work on the buffer between the replays
     del gr
 
+# the single-tensor quantizers (their groups of tiles start behind a probe of the packed output, as the decode's do)
+# from a captured graph, replayed with new inputs in the same buffers, two launches back to back per replay
+for ty, in_dt in ((8, t.float32), (3, t.float16), (15, t.bfloat16), (6, t.float32)):
+    n = g.block_elems(ty)
+    elems = 70 * 2048 + 3 * n                       # many groups of tiles and a ragged last tile
+    x = t.empty(elems, dtype=in_dt, device="cuda")
+    q = t.empty(elems // n * g.block_bytes(ty), dtype=t.uint8, device="cuda")
+    x.normal_()
+    side = t.cuda.Stream()
+    with t.cuda.stream(side):
+        g.quantize_slice(ty, q, x)                  # warm-up outside the capture
+    side.synchronize()
+    gr = t.cuda.CUDAGraph()
+    with t.cuda.graph(gr):
+        g.quantize_slice(ty, q, x)
+        g.quantize_slice(ty, q, x)
+    gen = t.Generator(device="cuda")
+    for rep in range(3):
+        gen.manual_seed(1234 + 10 * ty + rep)
+        x.copy_((t.randn(elems, device="cuda", generator=gen) * (0.02 + rep)).to(in_dt))
+        gr.replay()
+        t.cuda.synchronize()
+        host = x.cpu().numpy() if in_dt == t.float32 else x.view(t.int16).cpu().numpy().view(np.uint16)
+        want = o.quantize(ty, host, in_ty={t.float32: o.F32, t.float16: o.F16, t.bfloat16: o.BF16}[in_dt])
+        assert np.array_equal(q.cpu().numpy(), want), ("quantizer graph replay", ty, rep)
+        assert int(q.sum(dtype=t.int64).item()) >= 0   # eager work on the buffer between the replays
+    del gr
+
 # batch decode: one group of 11 tiles in 4 launches, several tensors with short tiles
 tensors, packed = [], []
 for i, blocks in enumerate((16 * 4 + 1, 7, 16 * 5, 16 + 3)):
