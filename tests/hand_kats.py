@@ -216,3 +216,33 @@ def cases():
         ty, blk, want = fn()
         out.append((ty, blk, np.array(want, dtype=np.float32)))
     return out
+
+
+# ---- quantizers: input blocks whose packed bytes were worked out by hand -----------------------------------
+# (ggml-quants/src/structs/q4_0.rs:23-44, q4_1.rs:23-47, q5_0.rs:26-58, q5_1.rs:26-62, q8_0.rs:23-41.)
+# Each case: (ggml type id, 32 float32 inputs, expected packed bytes).  None of the scaled values lies within 0.01
+# of a rounding boundary, so the last bit of 1 / delta cannot move a code.
+#   Q4_0, x = -16 .. 15: max_by_abs = -16 (the first element of largest magnitude), delta = -16 / -8 = 2 (f16 0x4000),
+#       code = trunc(min(x / 2 + 8.5, 15)) = (i + 1) // 2 capped at 15; byte j = code[j] | code[j + 16] << 4.
+#   Q5_0, x = -16 .. 15: delta = -16 / -16 = 1 (0x3C00), code = trunc(x + 16.5) = i; fifth bits of elements 16 .. 31
+#       -> qh = 0xFFFF0000; byte j = (j & 15) | (j & 15) << 4.
+#   Q4_1, x = 0 .. 31: min 0, delta = 31 / 15 = 2.0667 (f16: 2 * (1 + 34 / 1024) -> 0x4022), code =
+#       trunc(i * 15 / 31 + 0.5) = 0,0,1,1, ... ,15,15.
+#   Q5_1, x = 0 .. 31: min 0, delta = 1 (0x3C00), code = i, qh = 0xFFFF0000.
+#   Q8_0, x = 0 .. 31: delta = 31 / 127 = 0.244094 (f16: 2^-3 * (1 + 976 / 1024) -> 0x33D0), code = round(i * 127 / 31).
+Q8_0_CODES = [0, 4, 8, 12, 16, 20, 25, 29, 33, 37, 41, 45, 49, 53, 57, 61, 66, 70, 74, 78, 82, 86, 90, 94, 98, 102, 107,
+              111, 115, 119, 123, 127]
+
+
+def quantizer_cases():
+    ramp = np.arange(32, dtype=np.float32)
+    out = []
+    q4 = [min(15, (i + 1) // 2) for i in range(32)]
+    out.append((2, ramp - 16, np.array([0x00, 0x40] + [q4[j] | q4[j + 16] << 4 for j in range(16)], dtype=np.uint8)))
+    out.append((6, ramp - 16, np.array([0x00, 0x3C, 0x00, 0x00, 0xFF, 0xFF] + [0x11 * j for j in range(16)], dtype=np.uint8)))
+    q41 = [i // 2 for i in range(32)]
+    out.append((3, ramp, np.array([0x22, 0x40, 0x00, 0x00] + [q41[j] | q41[j + 16] << 4 for j in range(16)], dtype=np.uint8)))
+    out.append((7, ramp, np.array([0x00, 0x3C, 0x00, 0x00, 0x00, 0x00, 0xFF, 0xFF] + [0x11 * j for j in range(16)],
+                                  dtype=np.uint8)))
+    out.append((8, ramp, np.array([0xD0, 0x33] + Q8_0_CODES, dtype=np.uint8)))
+    return out

@@ -52,6 +52,18 @@ def check(oracle, ty, got, arr, kind):
                              f"{int(bad[0]) % bb}: got {got[b*bb:(b+1)*bb].tolist()} want {want[b*bb:(b+1)*bb].tolist()}")
 
 
+@pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
+def test_hand_kats(torch_cuda, oracle, kind):
+    """The quantizer blocks of tests/hand_kats.py (expected bytes typed in by hand): alone, and repeated so that
+    whole waves of them run together; their inputs are small integers, exact in f16 and bf16 as well."""
+    import hand_kats
+    for ty, x, want in hand_kats.quantizer_cases():
+        for reps in (1, 200):
+            arr = to_in(oracle, np.tile(x, reps), kind)
+            got = gpu_quantize(torch_cuda, ty, arr, kind)
+            assert got.tolist() == np.tile(want, reps).tolist(), (ty, kind, reps)
+
+
 @pytest.mark.parametrize("ty", QUANT)
 @pytest.mark.parametrize("kind", ["f32", "f16", "bf16"])
 def test_random_blocks(torch_cuda, oracle, ty, kind):

@@ -119,3 +119,12 @@ def test_threads_do_not_change_results(oracle):
     from gguf_amd import synth
     p = synth.random_blocks(12, 1000, 3)
     assert np.array_equal(oracle.dequantize(12, p, threads=1), oracle.dequantize(12, p, threads=7))
+
+
+@pytest.mark.parametrize("case", hand_kats.quantizer_cases(), ids=lambda c: f"type{c[0]}")
+def test_quantizer_hand_kats(oracle, case):
+    """Packed bytes typed in by hand (tests/hand_kats.py), not produced by any quantizer: header bits, the
+    max_by_abs sign rule (Q4_0 / Q5_0: the block's extreme is negative), nibble order, fifth-bit word."""
+    ty, x, want = case
+    got = oracle.quantize(ty, x)
+    assert got.tolist() == want.tolist()
