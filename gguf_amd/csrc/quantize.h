@@ -161,7 +161,8 @@ __device__ __forceinline__ float recip_fast(float d) {
 // half already agree; the step only needs ANY lane of the other half.  For M = 1, 2, 4, 8 that is
 // a DPP lane pattern inside a row of 16 (quad permutes, then the mirrors) carried by the arithmetic
 // instruction itself -- one instruction per step; written as asm because the compiler emits a copy, a DPP
-// move, a canonicalizing max and the operation (four) for the same step.  Wider steps use the generic shuffle.
+// move, a canonicalizing max and the operation (four) for the same step.  Wider steps (Q8K only, whose blocks span
+// 32 or 64 lanes) use the generic shuffle, except in max_by_abs, which swaps rows and halves with v_permlane*_swap.
 // Every lane of the wave is active wherever these run (quant_tile calls the encoders unconditionally), so each
 // DPP source lane is valid.  `s_nop 1`: a DPP operand written by the preceding vector instruction needs two
 // wait states, and the compiler does not look into asm.
