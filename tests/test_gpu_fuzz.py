@@ -34,7 +34,7 @@ def test_decode_matches_oracle(oracle, ty, out, blocks, offset, adversarial, see
 
 @settings(**_cfg)
 @given(ty=st.sampled_from(QUANT_TYPES), in_ty=st.sampled_from(["f32", "f16", "bf16"]),
-       blocks=st.one_of(st.integers(1, 70), st.integers(100, 1500)), kind=st.sampled_from(["normal", "wide", "special"]),
+       blocks=st.one_of(st.integers(1, 70), st.integers(100, 1500)), kind=st.sampled_from(["normal", "wide", "special", "extreme"]),
        seed=st.integers(0, 2 ** 31))
 def test_quantize_matches_oracle(oracle, ty, in_ty, blocks, kind, seed):
     import torch
@@ -55,6 +55,12 @@ def test_quantize_matches_oracle(oracle, ty, in_ty, blocks, kind, seed):
         x[pick == 4] = np.nan
         x[pick == 5] = x[0]                # ties of the maximum
         x[pick == 6] = -x[0]
+        x.view(np.uint32)[pick == 7] = 0x7FA00000 | rng.integers(0, 1 << 20, int((pick == 7).sum())).astype(np.uint32)  # signalling
+    elif kind == "extreme":                # one power of two per block, over the whole exponent range: blocks on both
+        if ty not in (1, 30):              # sides of the limits between which the encoders take their short divisions
+            xb = x.reshape(blocks, -1)
+            with np.errstate(over="ignore"):       # products beyond f32 become infinities: wanted
+                xb *= (np.float32(2.0) ** rng.integers(-126, 127, blocks).astype(np.float32))[:, None]
     tx = torch.from_numpy(x).cuda()
     if in_ty == "f16":
         tx = tx.to(torch.float16)
