@@ -1,0 +1,35 @@
+"""One-off soak of the quantizers against the CPU restatement used by the tests: random (type, input type, block
+count, kind of data, seed) cases through tests/test_gpu_fuzz.py's own case body, for a given number of seconds.
+Run on the GPU box: python tests/soak_quantize.py [seconds] [seed]   (not collected by pytest; 120 s = 130,000 cases)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import oracle  # noqa: E402
+import test_gpu_fuzz as F  # noqa: E402
+
+oracle.build()
+body = F.test_quantize_matches_oracle.hypothesis.inner_test
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+n = 0
+while time.time() < t_end:
+    ty = int(rng.choice(F.QUANT_TYPES))
+    in_ty = str(rng.choice(["f32", "f16", "bf16"]))
+    blocks = int(rng.integers(1, 70)) if rng.random() < 0.5 else int(rng.integers(100, 3000))
+    kind = str(rng.choice(["normal", "wide", "special", "extreme"]))
+    seed = int(rng.integers(0, 2 ** 31))
+    try:
+        body(oracle, ty, in_ty, blocks, kind, seed)
+    except AssertionError as e:
+        print("MISMATCH", ty, in_ty, blocks, kind, seed, e, flush=True)
+        sys.exit(1)
+    n += 1
+    if n % 500 == 0:
+        print(n, "cases", flush=True)
+print("OK", n, "cases")
