@@ -110,6 +110,74 @@ def check_arithmetic(funcs, names=None):
     return bad
 
 
+def _regs(tok):
+    """VGPR numbers named by an operand token: v7, |v7|, -v7, v[4:7]."""
+    tok = tok.strip().strip("|").lstrip("-").strip("|")
+    m = re.match(r"^v(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def _operands(ins):
+    """(mnemonic, [operand tokens]) of an instruction line; modifiers such as quad_perm:[..] stay out."""
+    ins = ins.split(";")[0].strip()
+    parts = ins.split(None, 1)
+    if len(parts) < 2:
+        return parts[0], []
+    ops, depth, cur = [], 0, ""
+    for ch in parts[1]:
+        if ch == "[":
+            depth += 1
+        elif ch == "]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            ops.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    ops.append(cur)
+    ops = [o.strip().split(" ")[0] if not o.strip().startswith("v[") else o.strip().split("]")[0] + "]" for o in ops]
+    return parts[0], ops
+
+
+TRANS = re.compile(r"^v_(rcp|rsq|sqrt|exp|log|sin|cos)(_iflag|_legacy)?_f(16|32|64)")
+
+
+def check_hand_placed_hazards(funcs):
+    """The library places instructions by hand (asm) whose hazards the compiler cannot see, so they are checked on
+    the generated code of every function:
+      * the result of a transcendental instruction (v_rcp_f32 ...) is not read by the very next instruction
+        (one wait state on this hardware; an s_nop in between provides it);
+      * a DPP instruction does not read a VGPR that one of the vector instructions within the two wait states in
+        front of it wrote (s_nop N counts N + 1)."""
+    bad = []
+    for name, body in funcs.items():
+        for i, ins in enumerate(body):
+            mn, ops = _operands(ins)
+            if TRANS.match(mn) and ops and i + 1 < len(body):
+                dst = _regs(ops[0])
+                nmn, nops = _operands(body[i + 1])
+                if not nmn.startswith("s_") and any(_regs(o) & dst for o in nops[1:] if nmn.startswith("v_")):
+                    bad.append(f"{name}: {body[i + 1]!r} reads the result of {ins!r} without a wait state")
+            if "_dpp" in mn and len(ops) >= 2:
+                src = _regs(ops[1])
+                states, j = 0, i - 1
+                while j >= 0 and states < 2:
+                    pmn, pops = _operands(body[j])
+                    if pmn == "s_nop":
+                        states += int(pops[0]) + 1 if pops else 1
+                    else:
+                        if pmn.startswith("v_") and pops and _regs(pops[0]) & src:
+                            bad.append(f"{name}: {ins!r} reads a register {body[j]!r} wrote {states} wait states earlier")
+                        states += 1
+                    j -= 1
+    return bad
+
+
 def check_group_start(funcs, names):
     """Every deq_one<F, O, ...> and quant_one<Q, In, ...>: before its first tile load (global_load_dwordx4) it must
     contain, in this order, a scalar ONE-dword load from memory other than the kernel arguments (the probe of the

@@ -38,6 +38,18 @@ def test_no_packed_f32_no_mixed_fma_and_fma_only_in_divisions(shipped):
     assert sum(1 for n in funcs if names[n].startswith("void ggq::quant_one<")) == 21
 
 
+def test_hand_placed_instructions_keep_their_wait_states(shipped):
+    funcs, _, _ = shipped
+    assert c.check_hand_placed_hazards(funcs) == []
+    # the check sees what it is meant to see
+    broken = {"f": ["v_rcp_f32 v1, v2", "v_fma_f32 v3, -v2, v1, 1.0"],
+              "g": ["v_max3_f32 v8, v8, |v7|, |v6|", "v_max_f32_dpp v8, v8, v8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"],
+              "h": ["v_rcp_f32 v1, v2", "s_nop 0", "v_fma_f32 v3, -v2, v1, 1.0", "v_mov_b32_e32 v8, v3", "s_nop 1",
+                    "v_max_f32_dpp v8, v8, v8 row_mirror row_mask:0xf bank_mask:0xf"]}
+    found = c.check_hand_placed_hazards(broken)
+    assert len(found) == 2 and found[0].startswith("f:") and found[1].startswith("g:")
+
+
 def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
     funcs, _, names = shipped
     assert c.check_group_start(funcs, names) == []
