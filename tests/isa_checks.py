@@ -153,7 +153,9 @@ def check_hand_placed_hazards(funcs):
       * the result of a transcendental instruction (v_rcp_f32 ...) is not read by the very next instruction
         (one wait state on this hardware; an s_nop in between provides it);
       * a DPP instruction does not read a VGPR that one of the vector instructions within the two wait states in
-        front of it wrote (s_nop N counts N + 1)."""
+        front of it wrote (s_nop N counts N + 1);
+      * a hand-placed v_cndmask_b32 does not take its lane mask from scalar registers that a VECTOR instruction
+        wrote within two wait states (the masks of max_by_abs come out of scalar mask arithmetic)."""
     bad = []
     for name, body in funcs.items():
         for i, ins in enumerate(body):
@@ -163,6 +165,21 @@ def check_hand_placed_hazards(funcs):
                 nmn, nops = _operands(body[i + 1])
                 if not nmn.startswith("s_") and any(_regs(o) & dst for o in nops[1:] if nmn.startswith("v_")):
                     bad.append(f"{name}: {body[i + 1]!r} reads the result of {ins!r} without a wait state")
+            if mn == "v_cndmask_b32" and len(ops) == 4:      # no _e32 / _e64 suffix: placed by hand (asm)
+                m = re.match(r"^s\[(\d+):(\d+)\]$", ops[3])
+                mask = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+                states, j = 0, i - 1
+                while j >= 0 and states < 2:
+                    pmn, pops = _operands(body[j])
+                    if pmn == "s_nop":
+                        states += int(pops[0]) + 1 if pops else 1
+                    else:
+                        pm = re.match(r"^s\[(\d+):(\d+)\]$", pops[0]) if pops else None
+                        if pmn.startswith("v_") and pm and set(range(int(pm.group(1)), int(pm.group(2)) + 1)) & mask:
+                            bad.append(f"{name}: {ins!r} reads a mask that {body[j]!r} (a vector instruction) wrote "
+                                       f"{states} wait states earlier")
+                        states += 1
+                    j -= 1
             if "_dpp" in mn and len(ops) >= 2:
                 src = _regs(ops[1])
                 states, j = 0, i - 1

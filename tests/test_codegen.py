@@ -46,8 +46,11 @@ def test_hand_placed_instructions_keep_their_wait_states(shipped):
               "g": ["v_max3_f32 v8, v8, |v7|, |v6|", "v_max_f32_dpp v8, v8, v8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"],
               "h": ["v_rcp_f32 v1, v2", "s_nop 0", "v_fma_f32 v3, -v2, v1, 1.0", "v_mov_b32_e32 v8, v3", "s_nop 1",
                     "v_max_f32_dpp v8, v8, v8 row_mirror row_mask:0xf bank_mask:0xf"]}
+    broken["k"] = ["v_cmp_gt_f32_e64 s[6:7], |v12|, |v11|", "v_cndmask_b32 v11, v11, v12, s[6:7]"]
+    broken["l"] = ["v_cmp_gt_f32_e64 s[6:7], |v12|, |v11|", "s_or_b64 s[6:7], s[8:9], s[6:7]", "s_nop 0",
+                   "v_cndmask_b32 v11, v11, v12, s[6:7]"]
     found = c.check_hand_placed_hazards(broken)
-    assert len(found) == 2 and found[0].startswith("f:") and found[1].startswith("g:")
+    assert len(found) == 3 and found[0].startswith("f:") and found[1].startswith("g:") and found[2].startswith("k:")
 
 
 def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
