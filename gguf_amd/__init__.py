@@ -6,4 +6,4 @@ gguf_amd/libggq.so), with a host-side mirror of the reference crate's
 """
 from .quants import *  # noqa: F401,F403
 from .quants import (GGmlType, QuantizeError, Indivisible, LengthMismatch, Unsupported,  # noqa: F401
-                     DeviceError, Misaligned, dequantize_slice, quantize_slice, Batch, QuantBatch, Context)
+                     DeviceError, Misaligned, dequantize_slice, quantize_slice, selftest_fast_division, Batch, QuantBatch, Context)

@@ -206,6 +206,17 @@ def quantize_slice(ty, dst, src, stream=None):
         check(lib.ggq_quantize_slice(int(ty), int(in_ty), dp, blocks, sp, sn))
 
 
+def selftest_fast_division():
+    """ggq_selftest_fast_division on the current device: the quantizer kernels' short division sequences against the
+    general IEEE division for every float in their range (about a second).  Returns ({"a/15": n, "a/31": n,
+    "a/127": n, "a/-127": n, "1/d": n}, inputs tested per constant); every n must be 0 on a GPU the library
+    quantizes on (the reference divides with `/`: ggml-quants/src/structs/q8_0.rs:31-32 and the other formats)."""
+    bad = (ctypes.c_uint64 * 5)()
+    tested = ctypes.c_uint64(0)
+    check(lib.ggq_selftest_fast_division(bad, ctypes.byref(tested)))
+    return dict(zip(("a/15", "a/31", "a/127", "a/-127", "1/d"), (int(x) for x in bad))), int(tested.value)
+
+
 class _Block:
     """DataBlock (ggml-quants/src/lib.rs:11-21) + QuantExt for one block type."""
     TYPE = None
