@@ -108,6 +108,26 @@ int main(int argc, char **argv) {
             for (size_t i = 0; i < in.size(); ++i) CHECK(out16[i].bits == f16_bits(out[i]));
         }
     }
+    if (device) {
+        {   // a block whose packed bytes were worked out by hand (q8_0.rs:23-41): x = 0 .. 31, delta = 31 / 127 ->
+            // f16 0x33D0, code = round(i * 127 / 31)
+            static const int8_t want[N] = {0, 4, 8, 12, 16, 20, 25, 29, 33, 37, 41, 45, 49, 53, 57, 61, 66, 70, 74, 78, 82,
+                                           86, 90, 94, 98, 102, 107, 111, 115, 119, 123, 127};
+            std::vector<float> in(N);
+            for (size_t i = 0; i < N; ++i) in[i] = (float)i;
+            std::vector<Q8_0> q(1);
+            auto r = QuantExt<Q8_0, float>::quantize_slice({q.data(), q.size()}, {in.data(), in.size()});
+            CHECK(!r);
+            CHECK(q[0].delta.bits == 0x33D0);
+            for (size_t i = 0; i < N; ++i) CHECK(q[0].quants[i] == want[i]);
+        }
+        {   // the quantizer kernels' short divisions against the general division, every float in range, on this GPU
+            uint64_t bad[5] = {1, 1, 1, 1, 1}, tested = 0;
+            CHECK(ggq_selftest_fast_division(bad, &tested) == GGQ_OK);
+            CHECK(tested == 2 * (200ull * (1u << 23) + 1));
+            for (uint64_t b : bad) CHECK(b == 0);
+        }
+    }
     if (failures) std::printf("%d FAILED\n", failures);
     else std::printf("slice api ok (%s)\n", device ? "with device" : "no device");
     return failures ? 1 : 0;
