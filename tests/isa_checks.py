@@ -152,8 +152,9 @@ def check_hand_placed_hazards(funcs):
     the generated code of every function:
       * the result of a transcendental instruction (v_rcp_f32 ...) is not read by the very next instruction
         (one wait state on this hardware; an s_nop in between provides it);
-      * a DPP instruction does not read a VGPR that one of the vector instructions within the two wait states in
-        front of it wrote (s_nop N counts N + 1);
+      * a DPP instruction or a v_permlane*_swap does not read a VGPR that one of the vector instructions within the
+        two wait states in front of it wrote (s_nop N counts N + 1) -- the compiler pads for writers it can see, not
+        for a hand-placed one;
       * a hand-placed v_cndmask_b32 does not take its lane mask from scalar registers that a VECTOR instruction
         wrote within two wait states (the masks of max_by_abs come out of scalar mask arithmetic)."""
     bad = []
@@ -180,8 +181,9 @@ def check_hand_placed_hazards(funcs):
                                        f"{states} wait states earlier")
                         states += 1
                     j -= 1
-            if "_dpp" in mn and len(ops) >= 2:
-                src = _regs(ops[1])
+            if ("_dpp" in mn or mn.startswith("v_permlane")) and len(ops) >= 2:
+                # (the row / half swaps read and write both operands, and need the same two wait states)
+                src = _regs(ops[1]) | (_regs(ops[0]) if mn.startswith("v_permlane") else set())
                 states, j = 0, i - 1
                 while j >= 0 and states < 2:
                     pmn, pops = _operands(body[j])

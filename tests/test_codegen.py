@@ -49,8 +49,9 @@ def test_hand_placed_instructions_keep_their_wait_states(shipped):
     broken["k"] = ["v_cmp_gt_f32_e64 s[6:7], |v12|, |v11|", "v_cndmask_b32 v11, v11, v12, s[6:7]"]
     broken["l"] = ["v_cmp_gt_f32_e64 s[6:7], |v12|, |v11|", "s_or_b64 s[6:7], s[8:9], s[6:7]", "s_nop 0",
                    "v_cndmask_b32 v11, v11, v12, s[6:7]"]
+    broken["m"] = ["v_cndmask_b32 v11, v11, v12, s[4:5]", "s_nop 0", "v_permlane16_swap_b32_e32 v11, v12"]
     found = c.check_hand_placed_hazards(broken)
-    assert len(found) == 3 and found[0].startswith("f:") and found[1].startswith("g:") and found[2].startswith("k:")
+    assert [x[0] for x in found] == ["f", "g", "k", "m"]
 
 
 def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
