@@ -155,6 +155,8 @@ def check_hand_placed_hazards(funcs):
       * a DPP instruction or a v_permlane*_swap does not read a VGPR that one of the vector instructions within the
         two wait states in front of it wrote (s_nop N counts N + 1) -- the compiler pads for writers it can see, not
         for a hand-placed one;
+      * v_readfirstlane does not read a VGPR that the instruction right in front of it wrote (the group start's
+        opaque zero goes from a hand-placed v_and_b32 into a v_readfirstlane);
       * a hand-placed v_cndmask_b32 does not take its lane mask from scalar registers that a VECTOR instruction
         wrote within two wait states (the masks of max_by_abs come out of scalar mask arithmetic)."""
     bad = []
@@ -166,6 +168,10 @@ def check_hand_placed_hazards(funcs):
                 nmn, nops = _operands(body[i + 1])
                 if not nmn.startswith("s_") and any(_regs(o) & dst for o in nops[1:] if nmn.startswith("v_")):
                     bad.append(f"{name}: {body[i + 1]!r} reads the result of {ins!r} without a wait state")
+            if mn.startswith("v_readfirstlane") and len(ops) == 2 and i > 0:
+                pmn, pops = _operands(body[i - 1])
+                if pmn.startswith("v_") and pops and _regs(pops[0]) & _regs(ops[1]):
+                    bad.append(f"{name}: {ins!r} reads what {body[i - 1]!r} wrote without a wait state")
             if mn == "v_cndmask_b32" and len(ops) == 4:      # no _e32 / _e64 suffix: placed by hand (asm)
                 m = re.match(r"^s\[(\d+):(\d+)\]$", ops[3])
                 mask = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()

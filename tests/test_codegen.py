@@ -50,8 +50,10 @@ def test_hand_placed_instructions_keep_their_wait_states(shipped):
     broken["l"] = ["v_cmp_gt_f32_e64 s[6:7], |v12|, |v11|", "s_or_b64 s[6:7], s[8:9], s[6:7]", "s_nop 0",
                    "v_cndmask_b32 v11, v11, v12, s[6:7]"]
     broken["m"] = ["v_cndmask_b32 v11, v11, v12, s[4:5]", "s_nop 0", "v_permlane16_swap_b32_e32 v11, v12"]
+    broken["n"] = ["v_and_b32 v1, 0, v1", "v_readfirstlane_b32 s4, v1"]
+    broken["o"] = ["v_and_b32 v1, 0, v1", "s_nop 0", "v_readfirstlane_b32 s4, v1"]
     found = c.check_hand_placed_hazards(broken)
-    assert [x[0] for x in found] == ["f", "g", "k", "m"]
+    assert [x[0] for x in found] == ["f", "g", "k", "m", "n"]
 
 
 def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
