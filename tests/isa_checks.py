@@ -272,6 +272,9 @@ def check_resources(res, names):
         m = re.match(r"^void ggq::(deq_one|deq_batch)<ggq::(\w+), ggq::(\w+),", d)
         if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0 or r.get("SGPRs Spill", 0) != 0:
             bad.append(f"{d}: scratch {r.get('ScratchSize')} B/lane, spills {r.get('VGPRs Spill')}/{r.get('SGPRs Spill')}")
+        if re.match(r"^void ggq::(quant_one|quant_batch|narrow_vec|widen_vec|permute_qk_rows|scale_vec)<", d) and \
+                r.get("Occupancy") != 8:
+            bad.append(f"{d}: {r.get('Occupancy')} waves/SIMD (VGPRs {r.get('VGPRs')}), 8 expected")
         if not m:
             continue
         seen += 1
