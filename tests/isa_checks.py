@@ -155,6 +155,8 @@ def check_hand_placed_hazards(funcs):
       * a DPP instruction or a v_permlane*_swap does not read a VGPR that one of the vector instructions within the
         two wait states in front of it wrote (s_nop N counts N + 1) -- the compiler pads for writers it can see, not
         for a hand-placed one;
+      * the result of a dot-product instruction (v_dot4 ...) is not read by a vector instruction within three wait
+        states (found the hard way: a hand-placed DPP add two states behind a v_dot4c read the old register);
       * v_readfirstlane does not read a VGPR that the instruction right in front of it wrote (the group start's
         opaque zero goes from a hand-placed v_and_b32 into a v_readfirstlane);
       * a hand-placed v_cndmask_b32 does not take its lane mask from scalar registers that a VECTOR instruction
@@ -168,6 +170,21 @@ def check_hand_placed_hazards(funcs):
                 nmn, nops = _operands(body[i + 1])
                 if not nmn.startswith("s_") and any(_regs(o) & dst for o in nops[1:] if nmn.startswith("v_")):
                     bad.append(f"{name}: {body[i + 1]!r} reads the result of {ins!r} without a wait state")
+            if mn.startswith("v_dot") and ops:              # a dot product's result: three wait states before a vector reader
+                dst = _regs(ops[0])
+                states, j = 0, i + 1
+                while j < len(body) and states < 3:
+                    nmn, nops = _operands(body[j])
+                    if nmn == "s_nop":
+                        states += int(nops[0]) + 1 if nops else 1
+                    else:
+                        # (the accumulate chain of the same kind of instruction is exempt: dot -> dot on its own dst)
+                        if nmn.startswith("v_") and not nmn.startswith("v_dot") and any(_regs(o) & dst for o in nops[1:]):
+                            bad.append(f"{name}: {body[j]!r} reads the result of {ins!r} after {states} wait states")
+                        if nmn.startswith("v_") and nops and _regs(nops[0]) & dst:
+                            break                           # overwritten: later readers see another value
+                        states += 1
+                    j += 1
             if mn.startswith("v_readfirstlane") and len(ops) == 2 and i > 0:
                 pmn, pops = _operands(body[i - 1])
                 if pmn.startswith("v_") and pops and _regs(pops[0]) & _regs(ops[1]):

@@ -52,8 +52,10 @@ def test_hand_placed_instructions_keep_their_wait_states(shipped):
     broken["m"] = ["v_cndmask_b32 v11, v11, v12, s[4:5]", "s_nop 0", "v_permlane16_swap_b32_e32 v11, v12"]
     broken["n"] = ["v_and_b32 v1, 0, v1", "v_readfirstlane_b32 s4, v1"]
     broken["o"] = ["v_and_b32 v1, 0, v1", "s_nop 0", "v_readfirstlane_b32 s4, v1"]
+    broken["p"] = ["v_dot4c_i32_i8_e32 v4, 0x1010101, v3", "s_nop 1", "v_add_u32_dpp v4, v4, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"]
+    broken["q"] = ["v_dot4c_i32_i8_e32 v4, 0x1010101, v3", "s_nop 2", "v_add_u32_dpp v4, v4, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"]
     found = c.check_hand_placed_hazards(broken)
-    assert [x[0] for x in found] == ["f", "g", "k", "m", "n"]
+    assert [x[0] for x in found] == ["f", "g", "k", "m", "n", "p"]
 
 
 def test_group_start_is_a_scalar_probe_ahead_of_the_tile_loads(shipped):
